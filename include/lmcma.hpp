@@ -1,0 +1,133 @@
+// lmcma.hpp — host-side optimiser API of the MI355X LM-CMA path planner.
+//
+// Source-compatible with the reference's lmcma_path_planner/src/lmcma.hpp for
+// callers of class LMCMA (constructor :131-133, init :135,
+// getNextParameterVector :72, setEvaluationFeedback :73,
+// isBehaviorLearningDone :138, public counteval / BestF :64-65) and for the
+// free functions it declares (RNG :32-36, myqsort :37-38, covariance :248,
+// differentiationMatrix :250-251, invert / cholesky / applyCovL :252-254).
+// A caller written against the reference header compiles against this one
+// unchanged and links liblmcma_hip.so instead of lmcma.cpp.
+//
+// What runs where: the population work (LMCMA::sample and, with a trajectory
+// problem attached, cost evaluation, ranking and recombination) runs on the GPU
+// through the C ABI in lmcma_hip.h; the O(m^2 N) state update runs on the host
+// in fp64 in the reference's order of operations, or on the device when
+// useDeviceUpdate(true) is set.
+//
+// SepCMA and CMAChol (reference lmcma.hpp:152-239) are not provided.
+#ifndef LMCMA_AMD_LMCMA_HPP
+#define LMCMA_AMD_LMCMA_HPP
+
+#include <stdint.h>
+
+// ---- value/id pair and sort (reference lmcma.hpp:4-8, 37-38) ------------------
+typedef struct {
+    double value;
+    int id;
+} sortedvals;
+
+// ---- random number generator (reference lmcma.hpp:10-36) ----------------------
+typedef struct {
+    long int startseed;
+    long int aktseed;
+    long int aktrand;
+    long int *rgrand;
+    short flgstored;
+    double hold;
+} random_t;
+
+void random_exit(random_t *t);
+long random_Start(random_t *t, long unsigned inseed);
+long random_init(random_t *t, long unsigned inseed);
+double random_Uniform(random_t *t);
+double random_Gauss(random_t *t);
+int compare(const void *a, const void *b);
+void myqsort(int sz, double *arfitness, int *arindex, sortedvals *arr);
+
+// ---- trajectory problem scored on the device (no reference counterpart as a
+//      type; the ingredients are cited in lmcma_hip.h) ---------------------------
+struct LMCMATrajectoryProblem {
+    int dims = 2;                  // 1..3
+    int waypoints = 0;             // N = dims * waypoints, dimension-major rows
+    int nx = 0, ny = 1, nz = 1;    // grid extent, cells indexed [z][y][x]
+    int cell_type = 1;             // LMCMA_GRID_* of lmcma_hip.h (default: bytes)
+    const void *cells = nullptr;   // copied by setTrajectoryProblem
+    double c_obs = 1.0;            // cost of an occupied cell
+    double start[3] = {0, 0, 0};
+    double goal[3] = {0, 0, 0};
+    double w_len = 1.0, w_grid = 1000.0, w_smooth = 1.0;
+    int pad_mode = 0;              // LMCMA_PAD_ENDPOINT
+};
+
+class CMABase {
+public:
+    int counteval;
+    double BestF;
+
+    CMABase() : counteval(0), BestF(1.7976931348623157e308) {}
+    virtual ~CMABase() {}
+    virtual void init(int N) = 0;
+    virtual void getNextParameterVector(double *params, int N) = 0;
+    virtual void setEvaluationFeedback(double *feedbacks, int numFeedbacks) = 0;
+    virtual bool isBehaviorLearningDone() { return false; }
+};
+
+class LMCMA : public CMABase {
+public:
+    // Same parameters and defaults as the reference constructor.  The bound and
+    // parameter arrays are read, not owned; loBounds / hiBounds must stay valid
+    // for the lifetime of the object, as in the reference (lmcma.cpp:109-110).
+    LMCMA(double *initialParams, int lambda = 0, double *loBounds = 0, double *hiBounds = 0,
+          double sigma = 1.0, double *covariance = 0, int inseed = 0, bool verbose = false);
+    ~LMCMA();
+    void init(int N);
+    void getNextParameterVector(double *params, int N);
+    void setEvaluationFeedback(double *feedbacks, int numFeedbacks);
+    bool isBehaviorLearningDone();
+    void sample();
+    void update();
+
+    // ---- extensions; call before init() ----------------------------------------
+    void setDirectionVectors(int m);   // default: lambda, the reference's choice
+    void setDevice(int ordinal);       // default 0
+    void usePhiloxSampling(bool on);   // default: the reference's sequential RNG on the host
+    void useDeviceUpdate(bool on);     // default: host fp64 update
+    // attaches the grid cost; evaluatePopulation()/step() then score on the GPU
+    void setTrajectoryProblem(const LMCMATrajectoryProblem &problem);
+
+    // ---- batched generation step (after init()) ----------------------------------
+    // scores every candidate of the current population on the device and feeds
+    // the costs back, which runs update() and sample() like the lambda-th
+    // setEvaluationFeedback call does.
+    void evaluatePopulation();
+    void step(int generations = 1) { for (int g = 0; g < generations; ++g) evaluatePopulation(); }
+
+    // ---- state readers ----------------------------------------------------------------
+    int dimension() const;
+    int populationSize() const;
+    int directionVectors() const;
+    int generation() const;
+    double stepSize() const;
+    void mean(double *xmean_out) const;                 // [N]
+    void population(double *rows_out) const;            // [lambda][N]
+    void lastCosts(double *costs_out) const;            // [lambda], candidate order
+    const char *lastError() const;                      // "" when no call has failed
+
+    struct Impl;
+
+private:
+    LMCMA(const LMCMA &);
+    LMCMA &operator=(const LMCMA &);
+    Impl *impl;
+};
+
+// ---- smoothness matrices (reference lmcma.hpp:241-254) -------------------------
+void covariance(int num_dims, int num_waypoints, double *covariance);
+void differentiationMatrix(int num_time_steps, int order, double dt, double *diff_matrix,
+                           int rowLen = -1);
+void invert(double *A, double *Ainv, int N);
+void cholesky(double *C, double *L, int N);
+void applyCovL(double *L, double *z, int N);
+
+#endif  // LMCMA_AMD_LMCMA_HPP

@@ -1,0 +1,218 @@
+/*
+ * lmcma_hip.h — C ABI of the MI355X (gfx950) LM-CMA population path.
+ *
+ * The reference optimiser has no FFI: callers include lmcma.hpp and link
+ * lmcma.cpp (lmcma_path_planner/CMakeLists.txt:39).  The functions below are
+ * what a reference-side binding calls from inside LMCMA::sample(),
+ * LMCMA::update() and CMABase::setEvaluationFeedback() to run the population
+ * work on the GPU.  Each entry point names the reference code it replaces as
+ *   L/ = lmcma_path_planner/src/
+ *   S/ = sample_based_optimisation_based_path_planner/src/
+ *
+ * Conventions
+ *   - plain C types only; every function returns LMCMA_HIP_OK (0) or a negative
+ *     error code, and lmcma_hip_last_error() returns the message of the calling
+ *     thread's last failure.  No exception crosses this boundary.
+ *   - one context owns one HIP stream (its own, or the caller's) and one set of
+ *     device buffers.  A context is not re-entrant; distinct contexts are
+ *     independent, like distinct LMCMA objects in the reference
+ *     (RNG state is per instance, L/lmcma.hpp:62).
+ *   - host pointers are caller-owned and are copied before the call returns
+ *     unless a function says otherwise.
+ *   - candidate rows hold n_params = dims * waypoints values, dimension-major
+ *     ([dim0: wp0..wpW-1 | dim1: ...], the block layout of L/lmcma.cpp:786-791),
+ *     and the population is row-major [lambda][n_params] like arx
+ *     (L/lmcma.cpp:138,308).
+ */
+#ifndef LMCMA_HIP_H
+#define LMCMA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMCMA_HIP_OK 0
+#define LMCMA_HIP_ERR_ARG (-1)         /* invalid argument                      */
+#define LMCMA_HIP_ERR_RUNTIME (-2)     /* a HIP runtime call failed             */
+#define LMCMA_HIP_ERR_STATE (-3)       /* call made in the wrong order          */
+#define LMCMA_HIP_ERR_UNSUPPORTED (-4) /* size outside what the kernels handle  */
+
+enum { LMCMA_Z_HOST = 0, LMCMA_Z_PHILOX = 1 };
+enum { LMCMA_GRID_BITS = 0, LMCMA_GRID_U8 = 1, LMCMA_GRID_F32 = 2 };
+enum { LMCMA_PAD_ENDPOINT = 0, LMCMA_PAD_ZERO = 1 };
+enum { LMCMA_COST_TRAJECTORY = 0, LMCMA_COST_EXTERNAL = 1 };
+
+/* limits of the kernels (checked by lmcma_hip_create) */
+#define LMCMA_HIP_MAX_PARAMS 512
+#define LMCMA_HIP_MAX_VECTORS 64
+#define LMCMA_HIP_MAX_LAMBDA (1 << 20)
+
+typedef struct lmcma_hip_ctx lmcma_hip_ctx;
+
+typedef struct {
+    int32_t struct_size;     /* sizeof(lmcma_hip_config), for ABI checking           */
+    int32_t device;          /* HIP device ordinal                                   */
+    int32_t dims;            /* D in 1..3 for a trajectory cost; 0 = plain vector    */
+    int32_t waypoints;       /* W                                                    */
+    int32_t n_params;        /* N; must equal dims*waypoints when dims > 0           */
+    int32_t lambda_total;    /* population size over all contexts of one optimiser   */
+    int32_t lambda_local;    /* candidates this context samples and scores           */
+    int32_t first_candidate; /* global index of this context's candidate 0           */
+    int32_t m;               /* direction vectors kept (reference: = lambda,         */
+                             /* L/lmcma.cpp:266)                                     */
+    int32_t mu;              /* elites; reference: lambda/2 (L/lmcma.cpp:136)        */
+    int32_t z_source;        /* LMCMA_Z_HOST or LMCMA_Z_PHILOX                       */
+    int32_t cost_source;     /* LMCMA_COST_TRAJECTORY or LMCMA_COST_EXTERNAL         */
+    int32_t pad_mode;        /* acceleration stencil at the path ends                */
+    int32_t reserved;
+    uint64_t seed;           /* Philox key                                           */
+    double w_len, w_grid, w_smooth;
+    double start[3], goal[3];
+    void *stream;            /* hipStream_t to run on; NULL: the context makes one   */
+} lmcma_hip_config;
+
+const char *lmcma_hip_last_error(void);
+int lmcma_hip_version(void);
+
+/* Replaces the allocations of CMABase::init / LMCMA::init (L/lmcma.cpp:138-142,
+ * 274-290) with device buffers. */
+int lmcma_hip_create(const lmcma_hip_config *cfg, lmcma_hip_ctx **out);
+int lmcma_hip_destroy(lmcma_hip_ctx *ctx);
+
+/* The cost map the candidates are scored against: the role of EDT_Matrix
+ * (S/...path_planner.cpp:37) behind ValidityChecker::clearance (:605-628).
+ * cells is indexed [z][y][x] (row = y, col = x, :599-602).
+ *   LMCMA_GRID_BITS  uint32 words, cell c is bit (c & 31) of word c >> 5;
+ *                    an occupied cell costs c_obs, a free one 0
+ *   LMCMA_GRID_U8    one byte per cell, non-zero = occupied; packed to bits
+ *   LMCMA_GRID_F32   one float per cell holding the state cost itself,
+ *                    e.g. 1 / max(clearance, d_min)  (:667)                     */
+int lmcma_hip_set_grid(lmcma_hip_ctx *ctx, const void *cells, int nx, int ny,
+                       int nz, int cell_type, double c_obs);
+
+/* loBounds / hiBounds of the constructor (L/lmcma.hpp:131-133), applied like
+ * CMABase::applyBoundaries (L/lmcma.cpp:220-230).  Either may be NULL.         */
+int lmcma_hip_set_bounds(lmcma_hip_ctx *ctx, const double *lo, const double *hi);
+
+/* Uploads the search state LMCMA::sample reads (L/lmcma.cpp:301-311, 431-447):
+ * xmean[N], sigma, and the k active direction pairs in iterator order:
+ * V[k][N] = v_arr rows, PC[k][N] = pc_arr rows, nj[k] = Nj_arr entries,
+ * M = sqrt(1-c1).  The library folds the scalar recurrence of computeAz into
+ *   Az = M^k z + sum_t M^(k-1-t) nj[t] (V[t].z) PC[t].                         */
+int lmcma_hip_set_state(lmcma_hip_ctx *ctx, const double *xmean, double sigma,
+                        const double *V, const double *PC, const double *nj,
+                        int k, double M);
+
+/* LMCMA::sample (L/lmcma.cpp:301-311) for this context's candidates.
+ * z_host: [lambda_local][N] standard normals drawn by the caller (z_source
+ * HOST, e.g. from random_Gauss, L/lmcma.cpp:63-82, with applyCovL already
+ * applied); NULL with z_source PHILOX, where generation selects the stream.   */
+int lmcma_hip_sample(lmcma_hip_ctx *ctx, uint32_t generation, const double *z_host);
+
+/* The caller's loop body between getNextParameterVector and
+ * setEvaluationFeedback (L/example_lmcma.cpp:51-54), for the trajectory cost:
+ * length + grid + smoothness terms summed left to right like
+ * CMABase::setEvaluationFeedback (L/lmcma.cpp:186-188).                        */
+int lmcma_hip_evaluate(lmcma_hip_ctx *ctx);
+
+/* Costs computed by the caller (cost_source EXTERNAL): arfitness of
+ * L/lmcma.cpp:190 for candidates [first, first+count) of the whole population. */
+int lmcma_hip_set_costs(lmcma_hip_ctx *ctx, int first, int count, const double *costs);
+
+/* myqsort(lambda, arfitness, arindex, ...) (L/lmcma.cpp:91-104, called :315):
+ * ascending, equal costs keep candidate order.  Outputs (host, may be NULL):
+ * sorted_cost[lambda_total], perm[lambda_total].  Needs the costs of all
+ * lambda_total candidates (own ones from evaluate, others via set_costs or the
+ * device buffer LMCMA_BUF_COST_ALL).                                            */
+int lmcma_hip_select(lmcma_hip_ctx *ctx, float *sorted_cost, int32_t *perm);
+
+/* Weighted recombination of the mu best rows (L/lmcma.cpp:321-326) over the
+ * candidates this context owns; with lambda_local == lambda_total this is the
+ * new xmean.  weights[mu]; xmean_out[N] (host, may be NULL).                   */
+int lmcma_hip_recombine(lmcma_hip_ctx *ctx, const double *weights, double *xmean_out);
+
+/* CMABase::getNextParameterVector (L/lmcma.cpp:172-182) for a block of local
+ * candidates: out[count][N].                                                   */
+int lmcma_hip_get_rows(lmcma_hip_ctx *ctx, int first_local, int count, double *out);
+/* local costs, and the three unweighted terms (J_len, J_grid, J_smooth)       */
+int lmcma_hip_get_costs(lmcma_hip_ctx *ctx, int first_local, int count, double *out);
+int lmcma_hip_get_terms(lmcma_hip_ctx *ctx, int first_local, int count, double *out3);
+/* score caller-supplied rows (host, float, [count][N]) without touching the
+ * population; count <= lambda_local.  cost_out[count], terms_out[count][3] or NULL */
+int lmcma_hip_score_rows(lmcma_hip_ctx *ctx, const float *rows, int count,
+                         float *cost_out, float *terms_out);
+
+/* ---- device-resident optimiser: L/lmcma.cpp:313-424 without leaving the GPU -- */
+
+/* CMABase::init + LMCMA::init (L/lmcma.cpp:130-170, 262-296): xmean0[N] (the
+ * initialParams), sigma0; weights, mueff, c1, cc, K, M are derived inside.
+ * Does not sample.                                                             */
+int lmcma_hip_opt_init(lmcma_hip_ctx *ctx, const double *xmean0, double sigma0);
+
+/* n whole generations: sample -> evaluate -> select -> recombine -> update
+ * (the body of CMABase::setEvaluationFeedback's every-lambda-th call,
+ * L/lmcma.cpp:199-204, plus the caller's cost loop), queued on the stream.
+ * Needs lambda_local == lambda_total, z_source PHILOX, cost_source TRAJECTORY. */
+int lmcma_hip_run(lmcma_hip_ctx *ctx, int n_generations);
+
+/* The same generation in pieces, for a population sharded over contexts:
+ *   phase_local   : sample + evaluate own candidates  -> LMCMA_BUF_COST_LOCAL
+ *   (exchange costs into LMCMA_BUF_COST_ALL of every context)
+ *   phase_rank    : select over all costs + partial recombination of own elites
+ *                                                    -> LMCMA_BUF_PARTIAL_LOCAL
+ *   (exchange partial sums into LMCMA_BUF_PARTIAL_ALL, one row per context)
+ *   phase_update  : LMCMA::update's remainder, identical on every context      */
+int lmcma_hip_phase_local(lmcma_hip_ctx *ctx);
+int lmcma_hip_phase_rank(lmcma_hip_ctx *ctx);
+int lmcma_hip_phase_update(lmcma_hip_ctx *ctx, int n_partials);
+
+typedef struct {
+    int32_t itr;          /* generations completed (L/lmcma.hpp:60)              */
+    int32_t iterator_sz;  /* active direction vectors                            */
+    int64_t counteval;    /* L/lmcma.hpp:64                                      */
+    double best_f;        /* L/lmcma.hpp:65                                      */
+    double sigma;
+    double s;             /* success-rule accumulator                            */
+} lmcma_hip_opt_summary;
+
+/* synchronises the stream */
+int lmcma_hip_opt_get(lmcma_hip_ctx *ctx, lmcma_hip_opt_summary *summary,
+                      double *xmean /* [N] or NULL */);
+/* full fp64 state for parity checks; any pointer may be NULL.
+ * v_arr/pc_arr: [m][N] slot-indexed like the reference; nj/lj: [m];
+ * iterator: [m]; pc: [N]                                                       */
+int lmcma_hip_opt_get_vectors(lmcma_hip_ctx *ctx, double *pc, double *v_arr,
+                              double *pc_arr, double *nj, double *lj,
+                              int32_t *iterator);
+
+/* device buffers, for collectives run by the caller (RCCL through
+ * torch.distributed).  Valid until lmcma_hip_destroy.                          */
+enum {
+    LMCMA_BUF_ROWS_LOCAL = 0,    /* float  [lambda_local][ld]                    */
+    LMCMA_BUF_COST_LOCAL = 1,    /* float  [lambda_local] (aliases COST_ALL)     */
+    LMCMA_BUF_COST_ALL = 2,      /* float  [lambda_total]                        */
+    LMCMA_BUF_PARTIAL_LOCAL = 3, /* double [N]                                   */
+    LMCMA_BUF_PARTIAL_ALL = 4,   /* double [max_partials][N]                     */
+    LMCMA_BUF_XMEAN = 5,         /* double [N]                                   */
+    LMCMA_BUF_SORTED_COST = 6,   /* float  [lambda_total]                        */
+    LMCMA_BUF_PERM = 7           /* int32  [lambda_total]                        */
+};
+int lmcma_hip_buffer(lmcma_hip_ctx *ctx, int which, void **device_ptr, size_t *bytes);
+int lmcma_hip_row_stride(lmcma_hip_ctx *ctx); /* ld: floats between rows */
+int lmcma_hip_synchronize(lmcma_hip_ctx *ctx);
+
+/* kernel timing with HIP events on the context's stream: records around every
+ * kernel class while enabled; totals in milliseconds and launch counts.       */
+enum { LMCMA_K_SAMPLE = 0, LMCMA_K_COST = 1, LMCMA_K_SELECT = 2, LMCMA_K_RECOMBINE = 3,
+       LMCMA_K_UPDATE = 4, LMCMA_K_COUNT = 5 };
+int lmcma_hip_timing_enable(lmcma_hip_ctx *ctx, int on);
+int lmcma_hip_timing_get(lmcma_hip_ctx *ctx, double ms[LMCMA_K_COUNT],
+                         int64_t launches[LMCMA_K_COUNT]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMCMA_HIP_H */

@@ -1,0 +1,171 @@
+"""ctypes loader for liblmcma_hip.so (HIP kernels + C ABI + host optimiser).
+
+The library is the product: there is no Python or CPU fallback.  Importing this
+module raises if the shared object has not been built (``make -C
+lmcma_path_planner_amd/csrc`` or ``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblmcma_hip.so")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+c_int64_p = ctypes.POINTER(ctypes.c_int64)
+c_uint8_p = ctypes.POINTER(ctypes.c_uint8)
+
+
+class HipConfig(ctypes.Structure):
+    """lmcma_hip_config of include/lmcma_hip.h."""
+    _fields_ = [
+        ("struct_size", ctypes.c_int32),
+        ("device", ctypes.c_int32),
+        ("dims", ctypes.c_int32),
+        ("waypoints", ctypes.c_int32),
+        ("n_params", ctypes.c_int32),
+        ("lambda_total", ctypes.c_int32),
+        ("lambda_local", ctypes.c_int32),
+        ("first_candidate", ctypes.c_int32),
+        ("m", ctypes.c_int32),
+        ("mu", ctypes.c_int32),
+        ("z_source", ctypes.c_int32),
+        ("cost_source", ctypes.c_int32),
+        ("pad_mode", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("seed", ctypes.c_uint64),
+        ("w_len", ctypes.c_double),
+        ("w_grid", ctypes.c_double),
+        ("w_smooth", ctypes.c_double),
+        ("start", ctypes.c_double * 3),
+        ("goal", ctypes.c_double * 3),
+        ("stream", ctypes.c_void_p),
+    ]
+
+
+class OptSummary(ctypes.Structure):
+    """lmcma_hip_opt_summary of include/lmcma_hip.h."""
+    _fields_ = [
+        ("itr", ctypes.c_int32),
+        ("iterator_sz", ctypes.c_int32),
+        ("counteval", ctypes.c_int64),
+        ("best_f", ctypes.c_double),
+        ("sigma", ctypes.c_double),
+        ("s", ctypes.c_double),
+    ]
+
+
+class OptInfo(ctypes.Structure):
+    """lmcma_opt_info of include/lmcma_opt.h."""
+    _fields_ = [
+        ("n", ctypes.c_int32),
+        ("lambda_", ctypes.c_int32),
+        ("m", ctypes.c_int32),
+        ("generation", ctypes.c_int32),
+        ("counteval", ctypes.c_int64),
+        ("best_f", ctypes.c_double),
+        ("sigma", ctypes.c_double),
+    ]
+
+
+# every symbol include/lmcma_hip.h and include/lmcma_opt.h declare: (restype, argtypes)
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+SIGNATURES = {
+    # lmcma_hip.h
+    "lmcma_hip_last_error": (ctypes.c_char_p, []),
+    "lmcma_hip_version": (_i, []),
+    "lmcma_hip_create": (_i, [ctypes.POINTER(HipConfig), ctypes.POINTER(_vp)]),
+    "lmcma_hip_destroy": (_i, [_vp]),
+    "lmcma_hip_set_grid": (_i, [_vp, _vp, _i, _i, _i, _i, ctypes.c_double]),
+    "lmcma_hip_set_bounds": (_i, [_vp, c_double_p, c_double_p]),
+    "lmcma_hip_set_state": (_i, [_vp, c_double_p, ctypes.c_double, c_double_p, c_double_p, c_double_p, _i,
+                                 ctypes.c_double]),
+    "lmcma_hip_sample": (_i, [_vp, ctypes.c_uint32, c_double_p]),
+    "lmcma_hip_evaluate": (_i, [_vp]),
+    "lmcma_hip_set_costs": (_i, [_vp, _i, _i, c_double_p]),
+    "lmcma_hip_select": (_i, [_vp, c_float_p, c_int32_p]),
+    "lmcma_hip_recombine": (_i, [_vp, c_double_p, c_double_p]),
+    "lmcma_hip_get_rows": (_i, [_vp, _i, _i, c_double_p]),
+    "lmcma_hip_get_costs": (_i, [_vp, _i, _i, c_double_p]),
+    "lmcma_hip_get_terms": (_i, [_vp, _i, _i, c_double_p]),
+    "lmcma_hip_score_rows": (_i, [_vp, c_float_p, _i, c_float_p, c_float_p]),
+    "lmcma_hip_opt_init": (_i, [_vp, c_double_p, ctypes.c_double]),
+    "lmcma_hip_run": (_i, [_vp, _i]),
+    "lmcma_hip_phase_local": (_i, [_vp]),
+    "lmcma_hip_phase_rank": (_i, [_vp]),
+    "lmcma_hip_phase_update": (_i, [_vp, _i]),
+    "lmcma_hip_opt_get": (_i, [_vp, ctypes.POINTER(OptSummary), c_double_p]),
+    "lmcma_hip_opt_get_vectors": (_i, [_vp, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                       c_int32_p]),
+    "lmcma_hip_buffer": (_i, [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_size_t)]),
+    "lmcma_hip_row_stride": (_i, [_vp]),
+    "lmcma_hip_synchronize": (_i, [_vp]),
+    "lmcma_hip_timing_enable": (_i, [_vp, _i]),
+    "lmcma_hip_timing_get": (_i, [_vp, c_double_p, c_int64_p]),
+    # lmcma_opt.h
+    "lmcma_opt_last_error": (ctypes.c_char_p, []),
+    "lmcma_opt_create": (_i, [c_double_p, c_double_p, c_double_p, c_double_p, _i, _i, ctypes.c_double, _i, _i,
+                              ctypes.POINTER(_vp)]),
+    "lmcma_opt_destroy": (_i, [_vp]),
+    "lmcma_opt_set_options": (_i, [_vp, _i, _i, _i, _i]),
+    "lmcma_opt_set_problem": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_double, c_double_p, c_double_p,
+                                   ctypes.c_double, ctypes.c_double, ctypes.c_double, _i]),
+    "lmcma_opt_init": (_i, [_vp, _i]),
+    "lmcma_opt_ask": (_i, [_vp, c_double_p, _i]),
+    "lmcma_opt_tell": (_i, [_vp, c_double_p, _i]),
+    "lmcma_opt_done": (_i, [_vp]),
+    "lmcma_opt_step": (_i, [_vp, _i]),
+    "lmcma_opt_get_info": (_i, [_vp, ctypes.POINTER(OptInfo)]),
+    "lmcma_opt_get_mean": (_i, [_vp, c_double_p]),
+    "lmcma_opt_get_population": (_i, [_vp, c_double_p]),
+    "lmcma_opt_get_last_costs": (_i, [_vp, c_double_p]),
+    "lmcma_host_gauss_stream": (_i, [_i, _i, c_double_p]),
+    "lmcma_host_uniform_stream": (_i, [_i, _i, c_double_p]),
+    "lmcma_host_covariance": (_i, [_i, _i, c_double_p]),
+    "lmcma_host_differentiation_matrix": (_i, [_i, _i, ctypes.c_double, c_double_p, _i]),
+    "lmcma_host_cholesky": (_i, [c_double_p, c_double_p, _i]),
+    "lmcma_host_apply_cov_l": (_i, [c_double_p, c_double_p, _i]),
+    "lmcma_host_sort": (_i, [_i, c_double_p, c_int32_p]),
+    "lmcma_grid_two_bar": (_i, [_i, _i, c_uint8_p]),
+    "lmcma_grid_random_boxes": (_i, [_i, _i, _i, ctypes.c_uint64, ctypes.c_double, c_double_p, c_double_p,
+                                     c_uint8_p]),
+    "lmcma_grid_edt": (_i, [c_uint8_p, _i, _i, _i, c_float_p]),
+    "lmcma_grid_8ssedt": (_i, [c_uint8_p, _i, _i, c_int32_p, c_double_p]),
+    "lmcma_grid_state_cost": (_i, [c_float_p, ctypes.c_long, ctypes.c_double, c_float_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load liblmcma_hip.so once and attach the prototypes.  Raises if missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "liblmcma_hip.so is not built (%s): run `make -C lmcma_path_planner_amd/csrc` "
+            "or __graft_entry__.build(); there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header and library disagree
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+class LmcmaError(RuntimeError):
+    pass
+
+
+def check_hip(rc, what):
+    if rc != 0:
+        raise LmcmaError("%s failed (%d): %s" % (what, rc, load().lmcma_hip_last_error().decode()))
+
+
+def check_opt(rc, what):
+    if rc < 0:
+        raise LmcmaError("%s failed: %s" % (what, load().lmcma_opt_last_error().decode()))

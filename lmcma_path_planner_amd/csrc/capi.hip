@@ -1,0 +1,872 @@
+// C ABI of liblmcma_hip: context lifetime, host<->device plumbing and the
+// per-generation launch sequences.  Entry points are documented in lmcma_hip.h.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "device_types.hpp"
+
+using namespace lmcma;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return fail(LMCMA_HIP_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+__global__ void k_set_sample_scalars(SampleScalars *sc, float sigma, float mk, int k, int set_state,
+                                     uint32_t generation, int set_generation)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (set_state) {
+            sc->sigma = sigma;
+            sc->mk = mk;
+            sc->k = k;
+        }
+        if (set_generation) sc->generation = generation;
+    }
+}
+
+struct EventPair {
+    hipEvent_t a, b;
+    int cls;
+};
+
+constexpr int kMaxPartials = 64;
+constexpr int kGensPerGraph = 8;
+
+}  // namespace
+
+struct lmcma_hip_ctx {
+    lmcma_hip_config cfg{};
+    int N = 0, ld = 0, D = 0, W = 0, lambda = 0, nloc = 0, first = 0, m = 0, mu = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    float *rows = nullptr, *zbuf = nullptr, *cost_all = nullptr, *terms = nullptr;
+    float *sorted_cost = nullptr, *prev_sorted = nullptr;
+    int32_t *perm = nullptr;
+    uint64_t *keys = nullptr;
+    float *xmean_f = nullptr, *V_f = nullptr, *B_f = nullptr, *lo_f = nullptr, *hi_f = nullptr;
+    SampleScalars *sc = nullptr;
+    double *weights = nullptr, *block_partials = nullptr, *partial_local = nullptr,
+           *partial_all = nullptr, *xmean = nullptr, *pc = nullptr, *pc_arr = nullptr,
+           *v_arr = nullptr, *nj = nullptr, *lj = nullptr;
+    int32_t *t = nullptr, *vec = nullptr, *iterator = nullptr;
+    OptScalars *opt = nullptr;
+    float *scratch_rows = nullptr, *scratch_cost = nullptr, *scratch_terms = nullptr;
+
+    void *grid = nullptr;
+    size_t grid_bytes = 0;
+    int grid_type = -1, nx = 0, ny = 0, nz = 0, grid_words = 0;
+    float c_obs = 1.f, c_start = 0.f, c_goal = 0.f;
+    bool grid_lds = false;
+
+    bool have_state = false, have_weights = false, opt_ready = false;
+    bool sampled = false, costs_ready = false, selected = false;
+
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+
+    bool timing = false;
+    std::vector<EventPair> ev_pool;
+    size_t ev_used = 0;
+    double t_ms[LMCMA_K_COUNT] = {0, 0, 0, 0, 0};
+    int64_t t_n[LMCMA_K_COUNT] = {0, 0, 0, 0, 0};
+};
+
+namespace {
+
+template <typename T>
+hipError_t dalloc(T **p, size_t count)
+{
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T) + 16);
+    if (e == hipSuccess) e = hipMemset(*p, 0, count * sizeof(T) + 16);
+    return e;
+}
+
+void drop_graph(lmcma_hip_ctx *c)
+{
+    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+}
+
+int fold_events(lmcma_hip_ctx *c)
+{
+    if (c->ev_used == 0) return LMCMA_HIP_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b));
+        c->t_ms[c->ev_pool[i].cls] += ms;
+        c->t_n[c->ev_pool[i].cls] += 1;
+    }
+    c->ev_used = 0;
+    return LMCMA_HIP_OK;
+}
+
+// brackets one kernel class with a pair of events while timing is on
+struct Timed {
+    lmcma_hip_ctx *c;
+    EventPair *ev = nullptr;
+    Timed(lmcma_hip_ctx *ctx, int cls) : c(ctx)
+    {
+        if (!c->timing) return;
+        if (c->ev_used == c->ev_pool.size()) {
+            if (c->ev_pool.size() >= 4096) {
+                if (fold_events(c) != LMCMA_HIP_OK) return;
+            } else {
+                EventPair p;
+                if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+                c->ev_pool.push_back(p);
+            }
+        }
+        ev = &c->ev_pool[c->ev_used++];
+        ev->cls = cls;
+        (void)hipEventRecord(ev->a, c->stream);
+    }
+    ~Timed()
+    {
+        if (ev) (void)hipEventRecord(ev->b, c->stream);
+    }
+};
+
+CostParams cost_params(const lmcma_hip_ctx *c, const float *rows, int n_rows, float *cost, float *terms)
+{
+    CostParams p{};
+    p.rows = rows;
+    p.ld = c->ld;
+    p.n_rows = n_rows;
+    p.cost = cost;
+    p.terms = terms;
+    p.grid = c->grid;
+    p.grid_type = c->grid_type;
+    p.nx = c->nx; p.ny = c->ny; p.nz = c->nz;
+    p.c_obs = c->c_obs;
+    p.W = c->W;
+    for (int d = 0; d < 3; ++d) {
+        p.start[d] = (float)c->cfg.start[d];
+        p.goal[d] = (float)c->cfg.goal[d];
+    }
+    p.c_start = c->c_start;
+    p.c_goal = c->c_goal;
+    p.w_len = (float)c->cfg.w_len;
+    p.w_grid = (float)c->cfg.w_grid;
+    p.w_smooth = (float)c->cfg.w_smooth;
+    p.pad_zero = c->cfg.pad_mode == LMCMA_PAD_ZERO;
+    p.grid_words = c->grid_words;
+    return p;
+}
+
+int do_sample(lmcma_hip_ctx *c, const float *z)
+{
+    Timed tm(c, LMCMA_K_SAMPLE);
+    HIP_TRY(launch_sample(c->stream, c->rows, z, c->xmean_f, c->V_f, c->B_f, c->lo_f, c->hi_f, c->sc,
+                          c->ld, c->nloc, (uint32_t)c->first, c->cfg.seed));
+    c->sampled = true;
+    return LMCMA_HIP_OK;
+}
+
+int do_evaluate(lmcma_hip_ctx *c)
+{
+    Timed tm(c, LMCMA_K_COST);
+    CostParams p = cost_params(c, c->rows, c->nloc, c->cost_all + c->first, c->terms);
+    HIP_TRY(launch_cost(c->stream, p, c->D, c->grid_lds));
+    return LMCMA_HIP_OK;
+}
+
+int do_select(lmcma_hip_ctx *c)
+{
+    Timed tm(c, LMCMA_K_SELECT);
+    HIP_TRY(launch_select(c->stream, c->cost_all, c->lambda, c->keys, c->sorted_cost, c->perm));
+    c->selected = true;
+    return LMCMA_HIP_OK;
+}
+
+int do_recombine(lmcma_hip_ctx *c)
+{
+    Timed tm(c, LMCMA_K_RECOMBINE);
+    HIP_TRY(launch_recombine(c->stream, c->rows, c->ld, c->N, c->first, c->nloc, c->perm, c->weights,
+                             c->mu, c->block_partials, c->partial_local));
+    return LMCMA_HIP_OK;
+}
+
+int do_update(lmcma_hip_ctx *c, const double *partials, int n_partials)
+{
+    Timed tm(c, LMCMA_K_UPDATE);
+    UpdateArgs a{};
+    a.opt = c->opt;
+    a.sc = c->sc;
+    a.N = c->N; a.ld = c->ld; a.lambda = c->lambda; a.m = c->m;
+    a.partials = partials;
+    a.n_partials = n_partials;
+    a.sorted_cost = c->sorted_cost;
+    a.prev_sorted_cost = c->prev_sorted;
+    a.xmean = c->xmean; a.pc = c->pc;
+    a.pc_arr = c->pc_arr; a.v_arr = c->v_arr;
+    a.nj = c->nj; a.lj = c->lj;
+    a.t = c->t; a.vec = c->vec; a.iterator = c->iterator;
+    a.xmean_f = c->xmean_f; a.V_f = c->V_f; a.B_f = c->B_f;
+    HIP_TRY(launch_update(c->stream, a));
+    return LMCMA_HIP_OK;
+}
+
+int one_generation(lmcma_hip_ctx *c)
+{
+    int rc;
+    if ((rc = do_sample(c, nullptr)) != LMCMA_HIP_OK) return rc;
+    if ((rc = do_evaluate(c)) != LMCMA_HIP_OK) return rc;
+    if ((rc = do_select(c)) != LMCMA_HIP_OK) return rc;
+    if ((rc = do_recombine(c)) != LMCMA_HIP_OK) return rc;
+    return do_update(c, c->partial_local, 1);
+}
+
+int check_ctx(const lmcma_hip_ctx *c)
+{
+    if (!c) return fail(LMCMA_HIP_ERR_ARG, "null context");
+    hipError_t e = hipSetDevice(c->cfg.device);
+    if (e != hipSuccess) return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return LMCMA_HIP_OK;
+}
+
+#define CTX_TRY(c)                                  \
+    do {                                            \
+        int _rc = check_ctx(c);                     \
+        if (_rc != LMCMA_HIP_OK) return _rc;        \
+    } while (0)
+
+float host_grid_value(const lmcma_hip_ctx *c, const void *cells_host_bits_or_f32, const double *q)
+{
+    // the fixed endpoints' cell, with the same rounding as the kernel
+    auto cl = [](double v, int n) {
+        float f = fminf(fmaxf((float)v, 0.f), (float)(n - 1));
+        return (int)nearbyintf(f);
+    };
+    const int ix = cl(q[0], c->nx);
+    const int iy = c->D > 1 ? cl(q[1], c->ny) : 0;
+    const int iz = c->D > 2 ? cl(q[2], c->nz) : 0;
+    const long cell = ((long)iz * c->ny + iy) * c->nx + ix;
+    if (c->grid_type == LMCMA_GRID_BITS) {
+        const uint32_t *w = (const uint32_t *)cells_host_bits_or_f32;
+        return ((w[cell >> 5] >> (cell & 31)) & 1u) ? c->c_obs : 0.f;
+    }
+    return ((const float *)cells_host_bits_or_f32)[cell];
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *lmcma_hip_last_error(void) { return g_last_error.c_str(); }
+int lmcma_hip_version(void) { return 1; }
+
+int lmcma_hip_create(const lmcma_hip_config *cfg, lmcma_hip_ctx **out)
+{
+    if (!cfg || !out) return fail(LMCMA_HIP_ERR_ARG, "null argument");
+    if (cfg->struct_size != (int32_t)sizeof(lmcma_hip_config))
+        return fail(LMCMA_HIP_ERR_ARG, "lmcma_hip_config.struct_size does not match this library");
+    if (cfg->n_params < 1 || cfg->n_params > LMCMA_HIP_MAX_PARAMS)
+        return fail(LMCMA_HIP_ERR_UNSUPPORTED, "n_params must be in [1, 512]");
+    if (cfg->dims < 0 || cfg->dims > 3) return fail(LMCMA_HIP_ERR_ARG, "dims must be 0..3");
+    if (cfg->dims > 0 && (cfg->waypoints < 1 || cfg->dims * cfg->waypoints != cfg->n_params))
+        return fail(LMCMA_HIP_ERR_ARG, "n_params must equal dims * waypoints");
+    if (cfg->dims == 0 && cfg->cost_source != LMCMA_COST_EXTERNAL)
+        return fail(LMCMA_HIP_ERR_ARG, "a plain vector problem (dims = 0) needs cost_source EXTERNAL");
+    if (cfg->lambda_total < 2 || cfg->lambda_total > LMCMA_HIP_MAX_LAMBDA)
+        return fail(LMCMA_HIP_ERR_UNSUPPORTED, "lambda_total must be in [2, 2^20]");
+    if (cfg->lambda_local < 1 || cfg->first_candidate < 0 ||
+        cfg->first_candidate + cfg->lambda_local > cfg->lambda_total)
+        return fail(LMCMA_HIP_ERR_ARG, "local candidate range lies outside the population");
+    if (cfg->m < 1 || cfg->m > LMCMA_HIP_MAX_VECTORS)
+        return fail(LMCMA_HIP_ERR_UNSUPPORTED, "m must be in [1, 64]");
+    if (cfg->mu < 1 || cfg->mu > cfg->lambda_total) return fail(LMCMA_HIP_ERR_ARG, "mu must be in [1, lambda]");
+    if (cfg->z_source != LMCMA_Z_HOST && cfg->z_source != LMCMA_Z_PHILOX)
+        return fail(LMCMA_HIP_ERR_ARG, "unknown z_source");
+
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(LMCMA_HIP_ERR_RUNTIME, "no HIP device visible");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(LMCMA_HIP_ERR_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    lmcma_hip_ctx *c = new lmcma_hip_ctx();
+    c->cfg = *cfg;
+    c->N = cfg->n_params;
+    c->ld = (c->N + 3) & ~3;
+    c->D = cfg->dims;
+    c->W = cfg->waypoints;
+    c->lambda = cfg->lambda_total;
+    c->nloc = cfg->lambda_local;
+    c->first = cfg->first_candidate;
+    c->m = cfg->m;
+    c->mu = cfg->mu;
+    if (cfg->stream) {
+        c->stream = (hipStream_t)cfg->stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(LMCMA_HIP_ERR_RUNTIME, "hipStreamCreate failed"); }
+        c->own_stream = true;
+    }
+    const size_t ld = c->ld, N = c->N, nloc = c->nloc, lam = c->lambda, m = c->m;
+    hipError_t e = hipSuccess;
+    auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    A(dalloc(&c->rows, nloc * ld));
+    A(dalloc(&c->cost_all, lam));
+    A(dalloc(&c->terms, nloc * 3));
+    A(dalloc(&c->sorted_cost, lam));
+    A(dalloc(&c->prev_sorted, lam));
+    A(dalloc(&c->perm, lam));
+    A(dalloc(&c->keys, (size_t)select_num_tiles(c->lambda) * kSortTile));
+    A(dalloc(&c->xmean_f, ld));
+    A(dalloc(&c->V_f, m * ld));
+    A(dalloc(&c->B_f, m * ld));
+    A(dalloc(&c->lo_f, ld));
+    A(dalloc(&c->hi_f, ld));
+    A(dalloc(&c->sc, 1));
+    A(dalloc(&c->weights, (size_t)c->mu));
+    A(dalloc(&c->block_partials, (size_t)recombine_num_blocks(c->mu) * N));
+    A(dalloc(&c->partial_local, N));
+    A(dalloc(&c->partial_all, (size_t)kMaxPartials * N));
+    A(dalloc(&c->xmean, N));
+    A(dalloc(&c->pc, N));
+    A(dalloc(&c->pc_arr, m * N));
+    A(dalloc(&c->v_arr, m * N));
+    A(dalloc(&c->nj, m));
+    A(dalloc(&c->lj, m));
+    A(dalloc(&c->t, m));
+    A(dalloc(&c->vec, m));
+    A(dalloc(&c->iterator, m));
+    A(dalloc(&c->opt, 1));
+    if (e == hipSuccess) {
+        // no bounds until set_bounds: -inf / +inf
+        std::vector<float> lo(ld, -INFINITY), hi(ld, INFINITY);
+        A(hipMemcpy(c->lo_f, lo.data(), ld * sizeof(float), hipMemcpyHostToDevice));
+        A(hipMemcpy(c->hi_f, hi.data(), ld * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (e != hipSuccess) {
+        std::string msg = std::string("device allocation failed: ") + hipGetErrorString(e);
+        lmcma_hip_destroy(c);
+        return fail(LMCMA_HIP_ERR_RUNTIME, msg);
+    }
+    *out = c;
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_destroy(lmcma_hip_ctx *c)
+{
+    if (!c) return LMCMA_HIP_OK;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drop_graph(c);
+    for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    void *bufs[] = {c->rows, c->zbuf, c->cost_all, c->terms, c->sorted_cost, c->prev_sorted, c->perm,
+                    c->keys, c->xmean_f, c->V_f, c->B_f, c->lo_f, c->hi_f, c->sc, c->weights,
+                    c->block_partials, c->partial_local, c->partial_all, c->xmean, c->pc, c->pc_arr,
+                    c->v_arr, c->nj, c->lj, c->t, c->vec, c->iterator, c->opt, c->scratch_rows,
+                    c->scratch_cost, c->scratch_terms, c->grid};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_set_grid(lmcma_hip_ctx *c, const void *cells, int nx, int ny, int nz, int cell_type,
+                       double c_obs)
+{
+    CTX_TRY(c);
+    if (c->D < 1) return fail(LMCMA_HIP_ERR_STATE, "this context has no trajectory cost (dims = 0)");
+    if (!cells || nx < 1 || ny < 1 || nz < 1) return fail(LMCMA_HIP_ERR_ARG, "bad grid extent");
+    if (c->D < 3 && nz != 1) return fail(LMCMA_HIP_ERR_ARG, "nz must be 1 for a 1-D or 2-D problem");
+    if (c->D < 2 && ny != 1) return fail(LMCMA_HIP_ERR_ARG, "ny must be 1 for a 1-D problem");
+    const long cells_n = (long)nx * ny * nz;
+    if (cells_n > (1l << 30)) return fail(LMCMA_HIP_ERR_UNSUPPORTED, "grid larger than 2^30 cells");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);
+    if (c->grid) { (void)hipFree(c->grid); c->grid = nullptr; }
+
+    std::vector<uint32_t> packed;
+    const void *src = cells;
+    size_t bytes;
+    if (cell_type == LMCMA_GRID_BITS || cell_type == LMCMA_GRID_U8) {
+        // words padded to a multiple of 4 so the LDS copy can move 16 bytes per lane
+        const size_t words = (((size_t)cells_n + 31) / 32 + 3) & ~(size_t)3;
+        packed.assign(words, 0u);
+        if (cell_type == LMCMA_GRID_U8) {
+            const uint8_t *b = (const uint8_t *)cells;
+            for (long i = 0; i < cells_n; ++i)
+                if (b[i]) packed[i >> 5] |= 1u << (i & 31);
+        } else {
+            memcpy(packed.data(), cells, (((size_t)cells_n + 31) / 32) * sizeof(uint32_t));
+        }
+        src = packed.data();
+        bytes = words * sizeof(uint32_t);
+        c->grid_type = LMCMA_GRID_BITS;
+        c->grid_words = (int)words;
+    } else if (cell_type == LMCMA_GRID_F32) {
+        bytes = (size_t)cells_n * sizeof(float);
+        c->grid_type = LMCMA_GRID_F32;
+        c->grid_words = 0;
+    } else {
+        return fail(LMCMA_HIP_ERR_ARG, "unknown cell_type");
+    }
+    c->nx = nx; c->ny = ny; c->nz = nz;
+    c->c_obs = (float)c_obs;
+    HIP_TRY(hipMalloc(&c->grid, bytes + 16));
+    HIP_TRY(hipMemcpy(c->grid, src, bytes, hipMemcpyHostToDevice));
+    c->grid_bytes = bytes;
+    c->c_start = host_grid_value(c, src, c->cfg.start);
+    c->c_goal = host_grid_value(c, src, c->cfg.goal);
+    // Stage a bit grid in LDS when it fits beside the row tile (160 KiB per CU)
+    // and every block amortises the copy over enough candidates.
+    const size_t row_tile = (size_t)16 * c->ld * sizeof(float);
+    c->grid_lds = c->grid_type == LMCMA_GRID_BITS && bytes + row_tile <= 160 * 1024 &&
+                  (size_t)c->nloc * (size_t)(c->W + 2) >= 8 * (bytes / 16);
+    if (const char *force = getenv("LMCMA_HIP_GRID_LDS")) {
+        if (force[0] == '0') c->grid_lds = false;
+        if (force[0] == '1' && c->grid_type == LMCMA_GRID_BITS && bytes + row_tile <= 160 * 1024)
+            c->grid_lds = true;
+    }
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_set_bounds(lmcma_hip_ctx *c, const double *lo, const double *hi)
+{
+    CTX_TRY(c);
+    std::vector<float> l(c->ld, -INFINITY), h(c->ld, INFINITY);
+    // a bound that is not representable in float is moved inwards so that a
+    // clamped coordinate never leaves the caller's fp64 interval
+    for (int n = 0; n < c->N; ++n) {
+        if (lo) {
+            float f = (float)lo[n];
+            if ((double)f < lo[n]) f = nextafterf(f, INFINITY);
+            l[n] = f;
+        }
+        if (hi) {
+            float f = (float)hi[n];
+            if ((double)f > hi[n]) f = nextafterf(f, -INFINITY);
+            h[n] = f;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(c->lo_f, l.data(), c->ld * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->hi_f, h.data(), c->ld * sizeof(float), hipMemcpyHostToDevice));
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_set_state(lmcma_hip_ctx *c, const double *xmean, double sigma, const double *V,
+                        const double *PC, const double *nj, int k, double M)
+{
+    CTX_TRY(c);
+    if (!xmean) return fail(LMCMA_HIP_ERR_ARG, "xmean is null");
+    if (k < 0 || k > c->m) return fail(LMCMA_HIP_ERR_ARG, "k must be in [0, m]");
+    if (k > 0 && (!V || !PC || !nj)) return fail(LMCMA_HIP_ERR_ARG, "V, PC and nj are needed when k > 0");
+    const int ld = c->ld, N = c->N;
+    std::vector<float> xm(ld, 0.f), vf((size_t)std::max(k, 1) * ld, 0.f), bf((size_t)std::max(k, 1) * ld, 0.f);
+    for (int n = 0; n < N; ++n) xm[n] = (float)xmean[n];
+    for (int t = 0; t < k; ++t) {
+        double coef = nj[t];
+        for (int e = 0; e < k - 1 - t; ++e) coef *= M;
+        for (int n = 0; n < N; ++n) {
+            vf[(size_t)t * ld + n] = (float)V[(size_t)t * N + n];
+            bf[(size_t)t * ld + n] = (float)(coef * PC[(size_t)t * N + n]);
+        }
+    }
+    double mk = 1.0;
+    for (int e = 0; e < k; ++e) mk *= M;
+    // pageable sources: these copies complete for the host before returning
+    HIP_TRY(hipMemcpyAsync(c->xmean_f, xm.data(), ld * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (k > 0) {
+        HIP_TRY(hipMemcpyAsync(c->V_f, vf.data(), (size_t)k * ld * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->B_f, bf.data(), (size_t)k * ld * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(c->xmean, xmean, N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_set_sample_scalars, dim3(1), dim3(64), 0, c->stream, c->sc, (float)sigma,
+                       (float)mk, k, 1, 0u, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_state = true;
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_sample(lmcma_hip_ctx *c, uint32_t generation, const double *z_host)
+{
+    CTX_TRY(c);
+    if (!c->have_state && !c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "set_state or opt_init must come first");
+    if (c->cfg.z_source == LMCMA_Z_HOST && !z_host)
+        return fail(LMCMA_HIP_ERR_ARG, "z_source HOST needs z_host");
+    if (c->cfg.z_source == LMCMA_Z_PHILOX && z_host)
+        return fail(LMCMA_HIP_ERR_ARG, "z_source PHILOX takes no z_host");
+    const float *z = nullptr;
+    if (z_host) {
+        if (!c->zbuf) HIP_TRY(dalloc(&c->zbuf, (size_t)c->nloc * c->ld));
+        std::vector<float> zf((size_t)c->nloc * c->ld, 0.f);
+        for (int i = 0; i < c->nloc; ++i)
+            for (int n = 0; n < c->N; ++n)
+                zf[(size_t)i * c->ld + n] = (float)z_host[(size_t)i * c->N + n];
+        HIP_TRY(hipMemcpyAsync(c->zbuf, zf.data(), zf.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        z = c->zbuf;
+    }
+    hipLaunchKernelGGL(k_set_sample_scalars, dim3(1), dim3(64), 0, c->stream, c->sc, 0.f, 0.f, 0, 0,
+                       generation, 1);
+    HIP_TRY(hipGetLastError());
+    c->costs_ready = false;
+    c->selected = false;
+    return do_sample(c, z);
+}
+
+int lmcma_hip_evaluate(lmcma_hip_ctx *c)
+{
+    CTX_TRY(c);
+    if (c->cfg.cost_source != LMCMA_COST_TRAJECTORY)
+        return fail(LMCMA_HIP_ERR_STATE, "cost_source is EXTERNAL: use lmcma_hip_set_costs");
+    if (!c->grid) return fail(LMCMA_HIP_ERR_STATE, "set_grid must come first");
+    if (!c->sampled) return fail(LMCMA_HIP_ERR_STATE, "sample must come first");
+    int rc = do_evaluate(c);
+    if (rc == LMCMA_HIP_OK && c->nloc == c->lambda) c->costs_ready = true;
+    return rc;
+}
+
+int lmcma_hip_set_costs(lmcma_hip_ctx *c, int first, int count, const double *costs)
+{
+    CTX_TRY(c);
+    if (!costs || first < 0 || count < 1 || first + count > c->lambda)
+        return fail(LMCMA_HIP_ERR_ARG, "bad candidate range");
+    std::vector<float> f(count);
+    for (int i = 0; i < count; ++i) f[i] = (float)costs[i];
+    HIP_TRY(hipMemcpyAsync(c->cost_all + first, f.data(), count * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->costs_ready = true;
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_select(lmcma_hip_ctx *c, float *sorted_cost, int32_t *perm)
+{
+    CTX_TRY(c);
+    int rc = do_select(c);
+    if (rc != LMCMA_HIP_OK) return rc;
+    if (sorted_cost)
+        HIP_TRY(hipMemcpyAsync(sorted_cost, c->sorted_cost, c->lambda * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (perm)
+        HIP_TRY(hipMemcpyAsync(perm, c->perm, c->lambda * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_recombine(lmcma_hip_ctx *c, const double *weights, double *xmean_out)
+{
+    CTX_TRY(c);
+    if (!c->selected) return fail(LMCMA_HIP_ERR_STATE, "select must come first");
+    if (weights) {
+        HIP_TRY(hipMemcpyAsync(c->weights, weights, c->mu * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->have_weights = true;
+    }
+    if (!c->have_weights) return fail(LMCMA_HIP_ERR_STATE, "no recombination weights set");
+    int rc = do_recombine(c);
+    if (rc != LMCMA_HIP_OK) return rc;
+    if (xmean_out)
+        HIP_TRY(hipMemcpyAsync(xmean_out, c->partial_local, c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_get_rows(lmcma_hip_ctx *c, int first_local, int count, double *out)
+{
+    CTX_TRY(c);
+    if (!out || first_local < 0 || count < 1 || first_local + count > c->nloc)
+        return fail(LMCMA_HIP_ERR_ARG, "bad candidate range");
+    std::vector<float> tmp((size_t)count * c->ld);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), c->rows + (size_t)first_local * c->ld, tmp.size() * sizeof(float),
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < count; ++i)
+        for (int n = 0; n < c->N; ++n) out[(size_t)i * c->N + n] = (double)tmp[(size_t)i * c->ld + n];
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_get_costs(lmcma_hip_ctx *c, int first_local, int count, double *out)
+{
+    CTX_TRY(c);
+    if (!out || first_local < 0 || count < 1 || first_local + count > c->nloc)
+        return fail(LMCMA_HIP_ERR_ARG, "bad candidate range");
+    std::vector<float> tmp(count);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), c->cost_all + c->first + first_local, count * sizeof(float),
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < count; ++i) out[i] = (double)tmp[i];
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_get_terms(lmcma_hip_ctx *c, int first_local, int count, double *out3)
+{
+    CTX_TRY(c);
+    if (!out3 || first_local < 0 || count < 1 || first_local + count > c->nloc)
+        return fail(LMCMA_HIP_ERR_ARG, "bad candidate range");
+    std::vector<float> tmp((size_t)count * 3);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), c->terms + (size_t)first_local * 3, tmp.size() * sizeof(float),
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < tmp.size(); ++i) out3[i] = (double)tmp[i];
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_score_rows(lmcma_hip_ctx *c, const float *rows, int count, float *cost_out, float *terms_out)
+{
+    CTX_TRY(c);
+    if (c->D < 1 || !c->grid) return fail(LMCMA_HIP_ERR_STATE, "set_grid must come first");
+    if (!rows || !cost_out || count < 1 || count > c->nloc)
+        return fail(LMCMA_HIP_ERR_ARG, "count must be in [1, lambda_local]");
+    if (!c->scratch_rows) {
+        HIP_TRY(dalloc(&c->scratch_rows, (size_t)c->nloc * c->ld));
+        HIP_TRY(dalloc(&c->scratch_cost, (size_t)c->nloc));
+        HIP_TRY(dalloc(&c->scratch_terms, (size_t)c->nloc * 3));
+    }
+    std::vector<float> padded((size_t)count * c->ld, 0.f);
+    for (int i = 0; i < count; ++i)
+        memcpy(&padded[(size_t)i * c->ld], rows + (size_t)i * c->N, c->N * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(c->scratch_rows, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    CostParams p = cost_params(c, c->scratch_rows, count, c->scratch_cost, c->scratch_terms);
+    {
+        Timed tm(c, LMCMA_K_COST);
+        HIP_TRY(launch_cost(c->stream, p, c->D, c->grid_lds));
+    }
+    HIP_TRY(hipMemcpyAsync(cost_out, c->scratch_cost, count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (terms_out)
+        HIP_TRY(hipMemcpyAsync(terms_out, c->scratch_terms, (size_t)count * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LMCMA_HIP_OK;
+}
+
+/* ---- device-resident optimiser ------------------------------------------------ */
+
+int lmcma_hip_opt_init(lmcma_hip_ctx *c, const double *xmean0, double sigma0)
+{
+    CTX_TRY(c);
+    if (!xmean0 || !(sigma0 > 0.0)) return fail(LMCMA_HIP_ERR_ARG, "xmean0 and a positive sigma0 are needed");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);
+    const int N = c->N, mu = c->mu, m = c->m;
+    // weights and mueff, lmcma.cpp:144-156
+    std::vector<double> w(mu);
+    double sum = 0;
+    for (int i = 0; i < mu; ++i) {
+        w[i] = log((double)mu + 0.5) - log((double)(1 + i));
+        sum += w[i];
+    }
+    double mueff = 0;
+    for (int i = 0; i < mu; ++i) {
+        w[i] /= sum;
+        mueff += w[i] * w[i];
+    }
+    mueff = 1.0 / mueff;
+    OptScalars o{};
+    o.sigma = sigma0;
+    o.s = 0.0;
+    o.best_f = 1.7976931348623157e308;
+    o.counteval = 0;
+    o.itr = 0;
+    o.iterator_sz = 0;
+    o.mueff = mueff;
+    o.c1 = 1.0 / (10 * log((double)(N + 1)));  // lmcma.cpp:268
+    o.cc = 1.0 / m;                            // lmcma.cpp:269 with nvectors = m
+    o.cs = 0.3;
+    o.val_target = 0.25;                       // lmcma.cpp:238
+    o.K = 1 / sqrt(1 - o.c1);
+    o.M = sqrt(1 - o.c1);
+    HIP_TRY(hipMemcpy(c->opt, &o, sizeof(o), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->weights, w.data(), mu * sizeof(double), hipMemcpyHostToDevice));
+    c->have_weights = true;
+    HIP_TRY(hipMemcpy(c->xmean, xmean0, N * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<float> xm(c->ld, 0.f);
+    for (int n = 0; n < N; ++n) xm[n] = (float)xmean0[n];
+    HIP_TRY(hipMemcpy(c->xmean_f, xm.data(), c->ld * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(c->pc, 0, N * sizeof(double)));
+    HIP_TRY(hipMemset(c->pc_arr, 0, (size_t)m * N * sizeof(double)));
+    HIP_TRY(hipMemset(c->v_arr, 0, (size_t)m * N * sizeof(double)));
+    HIP_TRY(hipMemset(c->nj, 0, m * sizeof(double)));
+    HIP_TRY(hipMemset(c->lj, 0, m * sizeof(double)));
+    HIP_TRY(hipMemset(c->t, 0, m * sizeof(int32_t)));
+    HIP_TRY(hipMemset(c->vec, 0, m * sizeof(int32_t)));
+    HIP_TRY(hipMemset(c->iterator, 0, m * sizeof(int32_t)));
+    SampleScalars sc{(float)sigma0, 1.0f, 0, 0u};
+    HIP_TRY(hipMemcpy(c->sc, &sc, sizeof(sc), hipMemcpyHostToDevice));
+    c->opt_ready = true;
+    c->have_state = true;
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
+{
+    CTX_TRY(c);
+    if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
+    if (c->nloc != c->lambda) return fail(LMCMA_HIP_ERR_STATE, "run needs the whole population in one context");
+    if (c->cfg.z_source != LMCMA_Z_PHILOX || c->cfg.cost_source != LMCMA_COST_TRAJECTORY)
+        return fail(LMCMA_HIP_ERR_STATE, "run needs z_source PHILOX and cost_source TRAJECTORY");
+    if (!c->grid) return fail(LMCMA_HIP_ERR_STATE, "set_grid must come first");
+    if (n_generations < 0) return fail(LMCMA_HIP_ERR_ARG, "negative generation count");
+    int left = n_generations;
+    const bool use_graph = !c->timing && getenv("LMCMA_HIP_NO_GRAPH") == nullptr;
+    if (use_graph && left >= kGensPerGraph) {
+        if (!c->graph_exec) {
+            // one eager generation first: module load and LDS attribute calls stay out of the capture
+            int rc = one_generation(c);
+            if (rc != LMCMA_HIP_OK) return rc;
+            --left;
+            HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            int crc = LMCMA_HIP_OK;
+            for (int g = 0; g < kGensPerGraph && crc == LMCMA_HIP_OK; ++g) crc = one_generation(c);
+            hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
+            if (crc != LMCMA_HIP_OK) { drop_graph(c); return crc; }
+            if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
+            e = hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0);
+            if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+        }
+        while (left >= kGensPerGraph) {
+            HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+            left -= kGensPerGraph;
+        }
+    }
+    for (; left > 0; --left) {
+        int rc = one_generation(c);
+        if (rc != LMCMA_HIP_OK) return rc;
+    }
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_phase_local(lmcma_hip_ctx *c)
+{
+    CTX_TRY(c);
+    if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
+    if (!c->grid) return fail(LMCMA_HIP_ERR_STATE, "set_grid must come first");
+    if (c->cfg.z_source != LMCMA_Z_PHILOX) return fail(LMCMA_HIP_ERR_STATE, "phases need z_source PHILOX");
+    int rc = do_sample(c, nullptr);
+    if (rc != LMCMA_HIP_OK) return rc;
+    return do_evaluate(c);
+}
+
+int lmcma_hip_phase_rank(lmcma_hip_ctx *c)
+{
+    CTX_TRY(c);
+    if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
+    int rc = do_select(c);
+    if (rc != LMCMA_HIP_OK) return rc;
+    return do_recombine(c);
+}
+
+int lmcma_hip_phase_update(lmcma_hip_ctx *c, int n_partials)
+{
+    CTX_TRY(c);
+    if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
+    if (n_partials < 0 || n_partials > kMaxPartials) return fail(LMCMA_HIP_ERR_ARG, "n_partials must be in [0, 64]");
+    // n_partials = 0: a single context, its own partial sum is the new mean
+    if (n_partials == 0) return do_update(c, c->partial_local, 1);
+    return do_update(c, c->partial_all, n_partials);
+}
+
+int lmcma_hip_opt_get(lmcma_hip_ctx *c, lmcma_hip_opt_summary *summary, double *xmean)
+{
+    CTX_TRY(c);
+    if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
+    OptScalars o;
+    HIP_TRY(hipMemcpyAsync(&o, c->opt, sizeof(o), hipMemcpyDeviceToHost, c->stream));
+    if (xmean) HIP_TRY(hipMemcpyAsync(xmean, c->xmean, c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (summary) {
+        summary->itr = o.itr;
+        summary->iterator_sz = o.iterator_sz;
+        summary->counteval = o.counteval;
+        summary->best_f = o.best_f;
+        summary->sigma = o.sigma;
+        summary->s = o.s;
+    }
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_opt_get_vectors(lmcma_hip_ctx *c, double *pc, double *v_arr, double *pc_arr, double *nj,
+                              double *lj, int32_t *iterator)
+{
+    CTX_TRY(c);
+    const size_t N = c->N, m = c->m;
+    if (pc) HIP_TRY(hipMemcpyAsync(pc, c->pc, N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (v_arr) HIP_TRY(hipMemcpyAsync(v_arr, c->v_arr, m * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (pc_arr) HIP_TRY(hipMemcpyAsync(pc_arr, c->pc_arr, m * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (nj) HIP_TRY(hipMemcpyAsync(nj, c->nj, m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (lj) HIP_TRY(hipMemcpyAsync(lj, c->lj, m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (iterator) HIP_TRY(hipMemcpyAsync(iterator, c->iterator, m * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_buffer(lmcma_hip_ctx *c, int which, void **device_ptr, size_t *bytes)
+{
+    if (!c || !device_ptr) return fail(LMCMA_HIP_ERR_ARG, "null argument");
+    void *p = nullptr;
+    size_t b = 0;
+    switch (which) {
+        case LMCMA_BUF_ROWS_LOCAL: p = c->rows; b = (size_t)c->nloc * c->ld * sizeof(float); break;
+        case LMCMA_BUF_COST_LOCAL: p = c->cost_all + c->first; b = (size_t)c->nloc * sizeof(float); break;
+        case LMCMA_BUF_COST_ALL: p = c->cost_all; b = (size_t)c->lambda * sizeof(float); break;
+        case LMCMA_BUF_PARTIAL_LOCAL: p = c->partial_local; b = (size_t)c->N * sizeof(double); break;
+        case LMCMA_BUF_PARTIAL_ALL: p = c->partial_all; b = (size_t)kMaxPartials * c->N * sizeof(double); break;
+        case LMCMA_BUF_XMEAN: p = c->xmean; b = (size_t)c->N * sizeof(double); break;
+        case LMCMA_BUF_SORTED_COST: p = c->sorted_cost; b = (size_t)c->lambda * sizeof(float); break;
+        case LMCMA_BUF_PERM: p = c->perm; b = (size_t)c->lambda * sizeof(int32_t); break;
+        default: return fail(LMCMA_HIP_ERR_ARG, "unknown buffer id");
+    }
+    *device_ptr = p;
+    if (bytes) *bytes = b;
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_row_stride(lmcma_hip_ctx *c) { return c ? c->ld : 0; }
+
+int lmcma_hip_synchronize(lmcma_hip_ctx *c)
+{
+    CTX_TRY(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_timing_enable(lmcma_hip_ctx *c, int on)
+{
+    CTX_TRY(c);
+    int rc = fold_events(c);
+    if (rc != LMCMA_HIP_OK) return rc;
+    c->timing = on != 0;
+    if (on) {
+        for (int i = 0; i < LMCMA_K_COUNT; ++i) { c->t_ms[i] = 0; c->t_n[i] = 0; }
+    }
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_timing_get(lmcma_hip_ctx *c, double ms[LMCMA_K_COUNT], int64_t launches[LMCMA_K_COUNT])
+{
+    CTX_TRY(c);
+    int rc = fold_events(c);
+    if (rc != LMCMA_HIP_OK) return rc;
+    for (int i = 0; i < LMCMA_K_COUNT; ++i) {
+        if (ms) ms[i] = c->t_ms[i];
+        if (launches) launches[i] = c->t_n[i];
+    }
+    return LMCMA_HIP_OK;
+}
+
+}  // extern "C"

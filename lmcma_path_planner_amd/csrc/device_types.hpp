@@ -1,0 +1,90 @@
+// Internal declarations shared by the kernels and the C ABI of liblmcma_hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lmcma_hip.h"
+
+namespace lmcma {
+
+// Scalars the sampling kernel reads from device memory, so that a captured
+// graph of one generation can be replayed without patching kernel arguments.
+struct SampleScalars {
+    float sigma;          // step size
+    float mk;             // M^k, the factor on z itself in A z
+    int32_t k;            // active direction vectors
+    uint32_t generation;  // Philox stream selector
+};
+
+// fp64 optimiser state kept on the device (single copy per context).
+struct OptScalars {
+    double sigma;
+    double s;            // success-rule accumulator
+    double best_f;
+    long long counteval;
+    int32_t itr;
+    int32_t iterator_sz;
+    // constants derived once at init (L/lmcma.cpp:136-156, 266-272)
+    double mueff, c1, cc, cs, val_target, K, M;
+    int32_t imin_last;   // first recomputed vector of the last update (diagnostic)
+    int32_t pad;
+};
+
+struct CostParams {
+    const float *rows;   // [n_rows][ld]
+    int ld;
+    int n_rows;
+    float *cost;         // [n_rows]
+    float *terms;        // [n_rows][3] or nullptr
+    const void *grid;
+    int grid_type;       // LMCMA_GRID_BITS or LMCMA_GRID_F32
+    int nx, ny, nz;
+    float c_obs;
+    int W;
+    float start[3], goal[3];
+    float c_start, c_goal;   // grid value at the fixed endpoints
+    float w_len, w_grid, w_smooth;
+    int pad_zero;
+    int grid_words;      // uint32 words of a bit grid (0 when not staged)
+};
+
+// ---- launchers (each in the .hip file that defines its kernels) -------------
+hipError_t launch_sample(hipStream_t s, float *rows, const float *zbuf, const float *xmean,
+                         const float *V, const float *B, const float *lo, const float *hi,
+                         const SampleScalars *sc, int ld, int n_local, uint32_t first_candidate,
+                         uint64_t seed);
+
+// lds_grid: stage a bit grid in LDS when it fits
+hipError_t launch_cost(hipStream_t s, const CostParams &p, int dims, bool lds_grid);
+
+constexpr int kSortTile = 4096;
+int select_num_tiles(int lambda);
+// keys_ws: uint64 [num_tiles * kSortTile]
+hipError_t launch_select(hipStream_t s, const float *cost_all, int lambda, uint64_t *keys_ws,
+                         float *sorted_cost, int32_t *perm);
+
+constexpr int kRecombineRanksPerBlock = 32;
+int recombine_num_blocks(int mu);
+hipError_t launch_recombine(hipStream_t s, const float *rows, int ld, int N, int first_candidate,
+                            int n_local, const int32_t *perm, const double *weights, int mu,
+                            double *block_partials, double *partial_local);
+
+struct UpdateArgs {
+    OptScalars *opt;
+    SampleScalars *sc;
+    int N, ld, lambda, m;
+    const double *partials;  // [n_partials][N]
+    int n_partials;
+    const float *sorted_cost;   // [lambda] this generation, ascending
+    float *prev_sorted_cost;    // [lambda]
+    double *xmean, *pc;         // [N]
+    double *pc_arr, *v_arr;     // [m][N]
+    double *nj, *lj;            // [m]
+    int32_t *t, *vec, *iterator; // [m]
+    float *xmean_f;             // [ld]
+    float *V_f, *B_f;           // [m][ld] in iterator order, B = M^(k-1-t) nj pc
+};
+hipError_t launch_update(hipStream_t s, const UpdateArgs &a);
+
+}  // namespace lmcma

@@ -1,0 +1,214 @@
+// Trajectory cost kernel: one cost per candidate row.
+//
+// Stands in for the caller's evaluation loop between getNextParameterVector and
+// setEvaluationFeedback (lmcma_path_planner/src/example_lmcma.cpp:51-54).  The
+// reference never connects a trajectory cost to LM-CMA; the terms are assembled
+// from its planning ingredients (S/ = sample_based_optimisation_based_path_planner/src/
+// sample_based_optimisation_based_path_planner.cpp, L/ = lmcma_path_planner/src/lmcma.cpp):
+//   cell lookup with round-half-even, (row = y, col = x)      S/:591-603
+//   state cost read from the looked-up cell                   S/:605-628, 655-668
+//   path length                                               S/:634-639
+//   weighted sum of the objectives                            S/:677-690
+//   5-tap acceleration rule, truncated at the path ends       L/:763, 823-832
+//   the three terms summed left to right                      L/:186-188
+//
+// Path: node 0 = start, nodes 1..W = the row's waypoints, node W+1 = goal.
+//   J_len    = sum over the W+1 segments of their Euclidean length
+//   J_grid   = sum over segments of 1/2 (c(a) + c(b)) * length   (trapezoid)
+//   J_smooth = sum over waypoints and dimensions of acceleration^2
+//   cost     = w_len J_len + w_grid J_grid + w_smooth J_smooth
+//
+// Work split: G lanes own one candidate and lane l owns waypoints l, l+G, ...;
+// a waypoint's lane sums 1/2 c(node) (len_prev + len_next) — the trapezoid sum
+// regrouped per node, so every cell is looked up once — plus the endpoint nodes'
+// shares at the first and last waypoint.  Rows are staged through LDS with
+// coalesced 16-byte loads so the +-2 neighbour reads are conflict-free LDS
+// reads; a bit-packed occupancy grid can be staged beside them.
+#include "device_types.hpp"
+
+namespace lmcma {
+
+namespace {
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int s = G / 2; s >= 1; s >>= 1) v += __shfl_xor(v, s, G);
+    return v;
+}
+
+template <int D>
+__device__ __forceinline__ float grid_value(const CostParams &p, const uint32_t *bits,
+                                            const float *q)
+{
+    // clamp in float first: a NaN coordinate falls to cell 0, huge values saturate
+    const int ix = (int)rintf(fminf(fmaxf(q[0], 0.f), (float)(p.nx - 1)));
+    const int iy = (D > 1) ? (int)rintf(fminf(fmaxf(q[1], 0.f), (float)(p.ny - 1))) : 0;
+    const int iz = (D > 2) ? (int)rintf(fminf(fmaxf(q[2], 0.f), (float)(p.nz - 1))) : 0;
+    const int cell = (iz * p.ny + iy) * p.nx + ix;
+    if (p.grid_type == LMCMA_GRID_BITS)
+        return ((bits[cell >> 5] >> (cell & 31)) & 1u) ? p.c_obs : 0.f;
+    return reinterpret_cast<const float *>(p.grid)[cell];
+}
+
+template <int G, int D, bool GRID_LDS>
+__global__ __launch_bounds__(256) void k_cost(const CostParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int C = 256 / G;  // candidates per tile
+    const int W = p.W;
+    const int ld = p.ld;
+    float *srows = smem;  // [C][ld]
+    const uint32_t *bits;
+    if (GRID_LDS) {
+        uint32_t *sbits = reinterpret_cast<uint32_t *>(smem + C * ld);
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.grid);
+        uint4 *dst = reinterpret_cast<uint4 *>(sbits);
+        for (int i = threadIdx.x; i < (p.grid_words >> 2); i += 256) dst[i] = src[i];
+        bits = sbits;
+    } else {
+        bits = reinterpret_cast<const uint32_t *>(p.grid);
+    }
+
+    const int g = threadIdx.x / G;
+    const int lane = threadIdx.x % G;
+    const int ntiles = (p.n_rows + C - 1) / C;
+    constexpr float c_far = -1.0f / 12.0f, c_near = 16.0f / 12.0f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * C;
+        const int nrows = min(C, p.n_rows - row0);
+        __syncthreads();  // previous tile fully consumed (and the grid copy issued)
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(p.rows + (size_t)row0 * ld);
+            float4 *dst = reinterpret_cast<float4 *>(srows);
+            const int n4 = (nrows * ld) >> 2;
+            for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+        }
+        __syncthreads();
+
+        float j_len = 0.f, j_grid = 0.f, j_smooth = 0.f;
+        if (g < nrows) {
+            const float *row = srows + g * ld;
+            for (int k = lane; k < W; k += G) {
+                float q0[D], qm[D], qp[D];
+                float len_prev2 = 0.f, len_next2 = 0.f, acc2 = 0.f;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const float *r = row + d * W;
+                    const float v0 = r[k];
+                    const float vm1 = (k >= 1) ? r[k - 1] : p.start[d];
+                    const float vp1 = (k + 1 < W) ? r[k + 1] : p.goal[d];
+                    float sm1 = vm1, sp1 = vp1;
+                    float sm2 = (k >= 2) ? r[k - 2] : p.start[d];
+                    float sp2 = (k + 2 < W) ? r[k + 2] : p.goal[d];
+                    if (p.pad_zero) {
+                        if (k < 1) sm1 = 0.f;
+                        if (k < 2) sm2 = 0.f;
+                        if (k + 1 >= W) sp1 = 0.f;
+                        if (k + 2 >= W) sp2 = 0.f;
+                    }
+                    q0[d] = v0; qm[d] = vm1; qp[d] = vp1;
+                    const float dm = v0 - vm1, dp = vp1 - v0;
+                    len_prev2 = fmaf(dm, dm, len_prev2);
+                    len_next2 = fmaf(dp, dp, len_next2);
+                    // -1/12 s[k-2] + 16/12 s[k-1] - 30/12 s[k] + 16/12 s[k+1] - 1/12 s[k+2],
+                    // written on differences to s[k] (the five weights sum to zero)
+                    const float a = fmaf(c_far, (sm2 - v0) + (sp2 - v0), c_near * ((sm1 - v0) + (sp1 - v0)));
+                    acc2 = fmaf(a, a, acc2);
+                }
+                (void)qm; (void)qp;
+                const float len_prev = sqrtf(len_prev2);
+                const float len_next = sqrtf(len_next2);
+                const float cv = grid_value<D>(p, bits, q0);
+                float gl = cv * (0.5f * (len_prev + len_next));
+                float ll = len_next;
+                if (k == 0) {
+                    ll += len_prev;
+                    gl = fmaf(p.c_start, 0.5f * len_prev, gl);
+                }
+                if (k == W - 1) gl = fmaf(p.c_goal, 0.5f * len_next, gl);
+                j_len += ll;
+                j_grid += gl;
+                j_smooth += acc2;
+            }
+        }
+        j_len = group_sum<G>(j_len);
+        j_grid = group_sum<G>(j_grid);
+        j_smooth = group_sum<G>(j_smooth);
+        if (g < nrows && lane == 0) {
+            float total = p.w_len * j_len;
+            total += p.w_grid * j_grid;
+            total += p.w_smooth * j_smooth;
+            if (total != total) total = __builtin_inff();  // NaN ranks last
+            p.cost[row0 + g] = total;
+            if (p.terms) {
+                float *t = p.terms + 3 * (size_t)(row0 + g);
+                t[0] = j_len; t[1] = j_grid; t[2] = j_smooth;
+            }
+        }
+    }
+}
+
+template <int G, int D>
+hipError_t launch_gd(hipStream_t s, const CostParams &p, bool lds_grid)
+{
+    constexpr int C = 256 / G;
+    const int ntiles = (p.n_rows + C - 1) / C;
+    size_t lds = (size_t)C * p.ld * sizeof(float);
+    if (lds_grid) {
+        lds += (size_t)p.grid_words * sizeof(uint32_t);
+        // one block per CU re-uses its staged grid over several row tiles
+        const int blocks = min(ntiles, 256);
+        // raise the kernel's dynamic-LDS limit once per size (not a stream operation,
+        // so it is kept out of the steady-state launch path and of graph captures)
+        static size_t configured = 0;
+        if (lds > configured) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cost<G, D, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            configured = lds;
+        }
+        hipLaunchKernelGGL((k_cost<G, D, true>), dim3(blocks), dim3(256), lds, s, p);
+    } else {
+        const int blocks = min(ntiles, 2048);
+        hipLaunchKernelGGL((k_cost<G, D, false>), dim3(blocks), dim3(256), lds, s, p);
+    }
+    return hipGetLastError();
+}
+
+template <int D>
+hipError_t launch_d(hipStream_t s, const CostParams &p, bool lds_grid)
+{
+    // lanes per candidate: the smallest group that leaves the fewest idle lanes
+    const int W = p.W;
+    int G;
+    if (W % 64 == 0 || W > 96) G = 64;
+    else if (W % 32 == 0) G = 32;
+    else if (W % 16 == 0 || W < 16) G = 16;
+    else if (W <= 32) G = 32;
+    else G = 64;
+    switch (G) {
+        case 16: return launch_gd<16, D>(s, p, lds_grid);
+        case 32: return launch_gd<32, D>(s, p, lds_grid);
+        default: return launch_gd<64, D>(s, p, lds_grid);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_cost(hipStream_t s, const CostParams &p, int dims, bool lds_grid)
+{
+    if (p.n_rows <= 0) return hipSuccess;
+    if (p.W < 1 || (p.ld & 3) || dims * p.W > p.ld) return hipErrorInvalidValue;
+    if (lds_grid && (p.grid_type != LMCMA_GRID_BITS || (p.grid_words & 3))) return hipErrorInvalidValue;
+    switch (dims) {
+        case 1: return launch_d<1>(s, p, lds_grid);
+        case 2: return launch_d<2>(s, p, lds_grid);
+        case 3: return launch_d<3>(s, p, lds_grid);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace lmcma

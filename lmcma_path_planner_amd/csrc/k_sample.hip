@@ -1,0 +1,187 @@
+// Population sampling kernel: x_i = clamp(xmean + sigma * A z_i).
+//
+// Replaces the candidate loop of LMCMA::sample (lmcma_path_planner/src/lmcma.cpp:301-311),
+// computeAz (:431-447) and CMABase::applyBoundaries (:220-230).  The scalar
+// recurrence of computeAz, Az <- M Az + nj_t (v_t . z) pc_t, is unrolled to the
+// closed form
+//     A z = M^k z + sum_t (V_t . z) B_t,   B_t = M^(k-1-t) nj_t pc_t,
+// whose coefficients are folded into B on the producer side.
+//
+// Work split: 16 lanes own one candidate; lane l owns the float4 chunks
+// l, l+16, l+32, ... of the row, so one group reads and writes 256 contiguous
+// bytes per step and the four groups of a wave64 share the same V/B cache lines.
+// The k dot products are reduced over the 16 lanes with an xor butterfly, which
+// leaves bit-identical sums in every lane of the group.
+#include "device_types.hpp"
+
+namespace lmcma {
+
+namespace {
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Four standard normals for element quad `chunk` of (generation, candidate):
+// two Box-Muller transforms on u = ((r >> 8) + 0.5) 2^-24 in (0,1).
+__device__ __forceinline__ float4 philox_normals(uint32_t chunk, uint32_t candidate,
+                                                 uint32_t generation, uint32_t k0, uint32_t k1)
+{
+    uint32_t r[4];
+    philox4x32_10(chunk, candidate, generation, 0u, k0, k1, r);
+    const float scale = 1.0f / 16777216.0f;
+    const float u1a = ((float)(r[0] >> 8) + 0.5f) * scale;
+    const float u2a = ((float)(r[1] >> 8) + 0.5f) * scale;
+    const float u1b = ((float)(r[2] >> 8) + 0.5f) * scale;
+    const float u2b = ((float)(r[3] >> 8) + 0.5f) * scale;
+    const float ra = sqrtf(-2.0f * logf(u1a));
+    const float rb = sqrtf(-2.0f * logf(u1b));
+    float sa, ca, sb, cb;
+    sincospif(2.0f * u2a, &sa, &ca);
+    sincospif(2.0f * u2b, &sb, &cb);
+    return make_float4(ra * ca, ra * sa, rb * cb, rb * sb);
+}
+
+__device__ __forceinline__ float group16_sum(float v)
+{
+    v += __shfl_xor(v, 8, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 1, 16);
+    return v;
+}
+
+// J = float4 chunks per lane; the row stride ld (a multiple of 4) must be <= 64 J.
+template <int J>
+__global__ __launch_bounds__(256) void k_sample(float *__restrict__ rows,
+                                                const float *__restrict__ zbuf,
+                                                const float *__restrict__ xmean,
+                                                const float *__restrict__ V,
+                                                const float *__restrict__ B,
+                                                const float *__restrict__ lo,
+                                                const float *__restrict__ hi,
+                                                const SampleScalars *__restrict__ sc, int ld,
+                                                int n_local, uint32_t first_candidate,
+                                                uint32_t key0, uint32_t key1)
+{
+    const int lane = threadIdx.x & 15;
+    const int cand = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = cand < n_local;
+    const int c = live ? cand : n_local - 1;  // idle groups shadow the last row (shuffles need all lanes)
+    const float sigma = sc->sigma;
+    const float mk = sc->mk;
+    const int k = sc->k;
+    const uint32_t generation = sc->generation;
+    const int nchunks = ld >> 2;
+
+    float4 z[J], acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int chunk = j * 16 + lane;
+        if (chunk < nchunks) {
+            if (zbuf)
+                z[j] = reinterpret_cast<const float4 *>(zbuf + (size_t)c * ld)[chunk];
+            else
+                z[j] = philox_normals((uint32_t)chunk, first_candidate + (uint32_t)c, generation,
+                                      key0, key1);
+        } else {
+            z[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        acc[j] = make_float4(mk * z[j].x, mk * z[j].y, mk * z[j].z, mk * z[j].w);
+    }
+
+    for (int t = 0; t < k; ++t) {
+        const float4 *v = reinterpret_cast<const float4 *>(V + (size_t)t * ld);
+        const float4 *b = reinterpret_cast<const float4 *>(B + (size_t)t * ld);
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int chunk = j * 16 + lane;
+            if (chunk < nchunks) {
+                const float4 vv = v[chunk];
+                d = fmaf(vv.x, z[j].x, d);
+                d = fmaf(vv.y, z[j].y, d);
+                d = fmaf(vv.z, z[j].z, d);
+                d = fmaf(vv.w, z[j].w, d);
+            }
+        }
+        d = group16_sum(d);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int chunk = j * 16 + lane;
+            if (chunk < nchunks) {
+                const float4 bb = b[chunk];
+                acc[j].x = fmaf(d, bb.x, acc[j].x);
+                acc[j].y = fmaf(d, bb.y, acc[j].y);
+                acc[j].z = fmaf(d, bb.z, acc[j].z);
+                acc[j].w = fmaf(d, bb.w, acc[j].w);
+            }
+        }
+    }
+
+    if (!live) return;
+    float4 *out = reinterpret_cast<float4 *>(rows + (size_t)cand * ld);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int chunk = j * 16 + lane;
+        if (chunk < nchunks) {
+            const float4 xm = reinterpret_cast<const float4 *>(xmean)[chunk];
+            const float4 l4 = reinterpret_cast<const float4 *>(lo)[chunk];
+            const float4 h4 = reinterpret_cast<const float4 *>(hi)[chunk];
+            float4 x;
+            // max with the lower bound first, then min with the upper one (lmcma.cpp:222-229)
+            x.x = fminf(fmaxf(fmaf(sigma, acc[j].x, xm.x), l4.x), h4.x);
+            x.y = fminf(fmaxf(fmaf(sigma, acc[j].y, xm.y), l4.y), h4.y);
+            x.z = fminf(fmaxf(fmaf(sigma, acc[j].z, xm.z), l4.z), h4.z);
+            x.w = fminf(fmaxf(fmaf(sigma, acc[j].w, xm.w), l4.w), h4.w);
+            out[chunk] = x;
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_sample(hipStream_t s, float *rows, const float *zbuf, const float *xmean,
+                         const float *V, const float *B, const float *lo, const float *hi,
+                         const SampleScalars *sc, int ld, int n_local, uint32_t first_candidate,
+                         uint64_t seed)
+{
+    if (n_local <= 0) return hipSuccess;
+    if (ld <= 0 || (ld & 3) || ld > 512) return hipErrorInvalidValue;
+    const dim3 grid((n_local + 15) / 16), block(256);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const int J = (ld + 63) / 64;
+#define LMCMA_SAMPLE_CASE(JJ)                                                                  \
+    case JJ:                                                                                   \
+        hipLaunchKernelGGL(k_sample<JJ>, grid, block, 0, s, rows, zbuf, xmean, V, B, lo, hi, sc, \
+                           ld, n_local, first_candidate, k0, k1);                              \
+        break;
+    switch (J) {
+        LMCMA_SAMPLE_CASE(1)
+        LMCMA_SAMPLE_CASE(2)
+        LMCMA_SAMPLE_CASE(3)
+        LMCMA_SAMPLE_CASE(4)
+        LMCMA_SAMPLE_CASE(5)
+        LMCMA_SAMPLE_CASE(6)
+        LMCMA_SAMPLE_CASE(7)
+        LMCMA_SAMPLE_CASE(8)
+        default:
+            return hipErrorInvalidValue;
+    }
+#undef LMCMA_SAMPLE_CASE
+    return hipGetLastError();
+}
+
+}  // namespace lmcma
