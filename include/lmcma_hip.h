@@ -152,6 +152,11 @@ int lmcma_hip_score_rows(lmcma_hip_ctx *ctx, const float *rows, int count,
  * Does not sample.                                                             */
 int lmcma_hip_opt_init(lmcma_hip_ctx *ctx, const double *xmean0, double sigma0);
 
+/* Puts the optimiser back into the state the last lmcma_hip_opt_init left (a new
+ * LMCMA object with the same arguments, L/lmcma.cpp:233-239, 262-296), queued on
+ * the stream without synchronising: for planning query after query on one map. */
+int lmcma_hip_opt_reset(lmcma_hip_ctx *ctx);
+
 /* n whole generations: sample -> evaluate -> select -> recombine -> update
  * (the body of CMABase::setEvaluationFeedback's every-lambda-th call,
  * L/lmcma.cpp:199-204, plus the caller's cost loop), queued on the stream.
@@ -207,7 +212,7 @@ int lmcma_hip_synchronize(lmcma_hip_ctx *ctx);
 /* kernel timing with HIP events on the context's stream: records around every
  * kernel class while enabled; totals in milliseconds and launch counts.       */
 enum { LMCMA_K_SAMPLE = 0, LMCMA_K_COST = 1, LMCMA_K_SELECT = 2, LMCMA_K_RECOMBINE = 3,
-       LMCMA_K_UPDATE = 4, LMCMA_K_COUNT = 5 };
+       LMCMA_K_UPDATE = 4, LMCMA_K_GENERATE = 5 /* sample + cost fused */, LMCMA_K_COUNT = 6 };
 int lmcma_hip_timing_enable(lmcma_hip_ctx *ctx, int on);
 int lmcma_hip_timing_get(lmcma_hip_ctx *ctx, double ms[LMCMA_K_COUNT],
                          int64_t launches[LMCMA_K_COUNT]);

@@ -92,6 +92,7 @@ SIGNATURES = {
     "lmcma_hip_get_terms": (_i, [_vp, _i, _i, c_double_p]),
     "lmcma_hip_score_rows": (_i, [_vp, c_float_p, _i, c_float_p, c_float_p]),
     "lmcma_hip_opt_init": (_i, [_vp, c_double_p, ctypes.c_double]),
+    "lmcma_hip_opt_reset": (_i, [_vp]),
     "lmcma_hip_run": (_i, [_vp, _i]),
     "lmcma_hip_phase_local": (_i, [_vp]),
     "lmcma_hip_phase_rank": (_i, [_vp]),

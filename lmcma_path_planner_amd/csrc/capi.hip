@@ -43,6 +43,32 @@ __global__ void k_set_sample_scalars(SampleScalars *sc, float sigma, float mk, i
     }
 }
 
+// back to the state lmcma_hip_opt_init left: mean, step size, empty direction store
+__global__ void k_opt_reset(OptScalars *opt, SampleScalars *sc, const double *xmean0, double sigma0,
+                            double *xmean, float *xmean_f, double *pc, int N, int ld)
+{
+    for (int n = threadIdx.x; n < ld; n += blockDim.x) {
+        const double x = n < N ? xmean0[n] : 0.0;
+        if (n < N) {
+            xmean[n] = x;
+            pc[n] = 0.0;
+        }
+        xmean_f[n] = (float)x;
+    }
+    if (threadIdx.x == 0) {
+        opt->sigma = sigma0;
+        opt->s = 0.0;
+        opt->best_f = 1.7976931348623157e308;
+        opt->counteval = 0;
+        opt->itr = 0;
+        opt->iterator_sz = 0;
+        sc->sigma = (float)sigma0;
+        sc->mk = 1.0f;
+        sc->k = 0;
+        sc->generation = 0u;
+    }
+}
+
 struct EventPair {
     hipEvent_t a, b;
     int cls;
@@ -60,7 +86,11 @@ struct lmcma_hip_ctx {
     bool own_stream = false;
 
     float *rows = nullptr, *zbuf = nullptr, *cost_all = nullptr, *terms = nullptr;
-    float *sorted_cost = nullptr, *prev_sorted = nullptr;
+    float *sorted_cost = nullptr;            // = sorted_buf[parity], this generation's ascending costs
+    float *sorted_buf[2] = {nullptr, nullptr};
+    int parity = 0, graph_parity = 0;
+    bool warmed = false;
+    unsigned long long *psr_accum = nullptr;
     int32_t *perm = nullptr;
     uint64_t *keys = nullptr;
     float *xmean_f = nullptr, *V_f = nullptr, *B_f = nullptr, *lo_f = nullptr, *hi_f = nullptr;
@@ -71,12 +101,15 @@ struct lmcma_hip_ctx {
     int32_t *t = nullptr, *vec = nullptr, *iterator = nullptr;
     OptScalars *opt = nullptr;
     float *scratch_rows = nullptr, *scratch_cost = nullptr, *scratch_terms = nullptr;
+    double *xmean0 = nullptr;   // initial mean kept for lmcma_hip_opt_reset
+    double sigma0 = 1.0;
 
     void *grid = nullptr;
     size_t grid_bytes = 0;
     int grid_type = -1, nx = 0, ny = 0, nz = 0, grid_words = 0;
     float c_obs = 1.f, c_start = 0.f, c_goal = 0.f;
     bool grid_lds = false;
+    bool fused = true;   // sample + score in one kernel on the device-resident path
 
     bool have_state = false, have_weights = false, opt_ready = false;
     bool sampled = false, costs_ready = false, selected = false;
@@ -87,8 +120,8 @@ struct lmcma_hip_ctx {
     bool timing = false;
     std::vector<EventPair> ev_pool;
     size_t ev_used = 0;
-    double t_ms[LMCMA_K_COUNT] = {0, 0, 0, 0, 0};
-    int64_t t_n[LMCMA_K_COUNT] = {0, 0, 0, 0, 0};
+    double t_ms[LMCMA_K_COUNT] = {};
+    int64_t t_n[LMCMA_K_COUNT] = {};
 };
 
 namespace {
@@ -191,19 +224,43 @@ int do_evaluate(lmcma_hip_ctx *c)
     return LMCMA_HIP_OK;
 }
 
+// sample + score in one launch (device Philox stream only)
+int do_generate(lmcma_hip_ctx *c)
+{
+    Timed tm(c, LMCMA_K_GENERATE);
+    GenParams g{};
+    g.rows = c->rows;
+    g.xmean = c->xmean_f; g.V = c->V_f; g.B = c->B_f; g.lo = c->lo_f; g.hi = c->hi_f;
+    g.sc = c->sc;
+    g.ld = c->ld; g.n_local = c->nloc; g.m = c->m;
+    g.first_candidate = (uint32_t)c->first;
+    g.key0 = (uint32_t)c->cfg.seed;
+    g.key1 = (uint32_t)(c->cfg.seed >> 32);
+    g.cost = cost_params(c, c->rows, c->nloc, c->cost_all + c->first, c->terms);
+    HIP_TRY(launch_generate(c->stream, g, c->D, c->grid_lds));
+    c->sampled = true;
+    return LMCMA_HIP_OK;
+}
+
 int do_select(lmcma_hip_ctx *c)
 {
     Timed tm(c, LMCMA_K_SELECT);
-    HIP_TRY(launch_select(c->stream, c->cost_all, c->lambda, c->keys, c->sorted_cost, c->perm));
+    // the two sorted-cost buffers alternate: this generation's list is written beside last one's
+    c->parity ^= 1;
+    c->sorted_cost = c->sorted_buf[c->parity];
+    HIP_TRY(launch_select(c->stream, c->cost_all, c->lambda, c->keys, c->sorted_cost, c->perm,
+                          c->opt_ready ? c->opt : nullptr, c->sorted_buf[c->parity ^ 1], c->psr_accum));
     c->selected = true;
     return LMCMA_HIP_OK;
 }
 
-int do_recombine(lmcma_hip_ctx *c)
+// with_final: also reduce the block partials to partial_local (needed when the
+// partial sum leaves the context; k_update can add the block partials itself)
+int do_recombine(lmcma_hip_ctx *c, bool with_final)
 {
     Timed tm(c, LMCMA_K_RECOMBINE);
     HIP_TRY(launch_recombine(c->stream, c->rows, c->ld, c->N, c->first, c->nloc, c->perm, c->weights,
-                             c->mu, c->block_partials, c->partial_local));
+                             c->mu, c->block_partials, with_final ? c->partial_local : nullptr));
     return LMCMA_HIP_OK;
 }
 
@@ -217,7 +274,7 @@ int do_update(lmcma_hip_ctx *c, const double *partials, int n_partials)
     a.partials = partials;
     a.n_partials = n_partials;
     a.sorted_cost = c->sorted_cost;
-    a.prev_sorted_cost = c->prev_sorted;
+    a.psr_accum = c->psr_accum;
     a.xmean = c->xmean; a.pc = c->pc;
     a.pc_arr = c->pc_arr; a.v_arr = c->v_arr;
     a.nj = c->nj; a.lj = c->lj;
@@ -230,11 +287,15 @@ int do_update(lmcma_hip_ctx *c, const double *partials, int n_partials)
 int one_generation(lmcma_hip_ctx *c)
 {
     int rc;
-    if ((rc = do_sample(c, nullptr)) != LMCMA_HIP_OK) return rc;
-    if ((rc = do_evaluate(c)) != LMCMA_HIP_OK) return rc;
+    if (c->fused) {
+        if ((rc = do_generate(c)) != LMCMA_HIP_OK) return rc;
+    } else {
+        if ((rc = do_sample(c, nullptr)) != LMCMA_HIP_OK) return rc;
+        if ((rc = do_evaluate(c)) != LMCMA_HIP_OK) return rc;
+    }
     if ((rc = do_select(c)) != LMCMA_HIP_OK) return rc;
-    if ((rc = do_recombine(c)) != LMCMA_HIP_OK) return rc;
-    return do_update(c, c->partial_local, 1);
+    if ((rc = do_recombine(c, false)) != LMCMA_HIP_OK) return rc;
+    return do_update(c, c->block_partials, recombine_num_blocks(c->mu));
 }
 
 int check_ctx(const lmcma_hip_ctx *c)
@@ -329,10 +390,12 @@ int lmcma_hip_create(const lmcma_hip_config *cfg, lmcma_hip_ctx **out)
     A(dalloc(&c->rows, nloc * ld));
     A(dalloc(&c->cost_all, lam));
     A(dalloc(&c->terms, nloc * 3));
-    A(dalloc(&c->sorted_cost, lam));
-    A(dalloc(&c->prev_sorted, lam));
+    A(dalloc(&c->sorted_buf[0], lam + 4));
+    A(dalloc(&c->sorted_buf[1], lam + 4));
+    c->sorted_cost = c->sorted_buf[0];
+    A(dalloc(&c->psr_accum, 1));
     A(dalloc(&c->perm, lam));
-    A(dalloc(&c->keys, (size_t)select_num_tiles(c->lambda) * kSortTile));
+    A(dalloc(&c->keys, select_workspace_bytes(c->lambda) / sizeof(uint64_t) + 1));
     A(dalloc(&c->xmean_f, ld));
     A(dalloc(&c->V_f, m * ld));
     A(dalloc(&c->B_f, m * ld));
@@ -364,6 +427,7 @@ int lmcma_hip_create(const lmcma_hip_config *cfg, lmcma_hip_ctx **out)
         lmcma_hip_destroy(c);
         return fail(LMCMA_HIP_ERR_RUNTIME, msg);
     }
+    if (const char *f = getenv("LMCMA_HIP_FUSED")) c->fused = f[0] != '0';
     *out = c;
     return LMCMA_HIP_OK;
 }
@@ -375,11 +439,11 @@ int lmcma_hip_destroy(lmcma_hip_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graph(c);
     for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    void *bufs[] = {c->rows, c->zbuf, c->cost_all, c->terms, c->sorted_cost, c->prev_sorted, c->perm,
+    void *bufs[] = {c->rows, c->zbuf, c->cost_all, c->terms, c->sorted_buf[0], c->sorted_buf[1], c->psr_accum, c->perm,
                     c->keys, c->xmean_f, c->V_f, c->B_f, c->lo_f, c->hi_f, c->sc, c->weights,
                     c->block_partials, c->partial_local, c->partial_all, c->xmean, c->pc, c->pc_arr,
                     c->v_arr, c->nj, c->lj, c->t, c->vec, c->iterator, c->opt, c->scratch_rows,
-                    c->scratch_cost, c->scratch_terms, c->grid};
+                    c->scratch_cost, c->scratch_terms, c->grid, c->xmean0};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -580,7 +644,7 @@ int lmcma_hip_recombine(lmcma_hip_ctx *c, const double *weights, double *xmean_o
         c->have_weights = true;
     }
     if (!c->have_weights) return fail(LMCMA_HIP_ERR_STATE, "no recombination weights set");
-    int rc = do_recombine(c);
+    int rc = do_recombine(c, true);
     if (rc != LMCMA_HIP_OK) return rc;
     if (xmean_out)
         HIP_TRY(hipMemcpyAsync(xmean_out, c->partial_local, c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -662,7 +726,6 @@ int lmcma_hip_opt_init(lmcma_hip_ctx *c, const double *xmean0, double sigma0)
     CTX_TRY(c);
     if (!xmean0 || !(sigma0 > 0.0)) return fail(LMCMA_HIP_ERR_ARG, "xmean0 and a positive sigma0 are needed");
     HIP_TRY(hipStreamSynchronize(c->stream));
-    drop_graph(c);
     const int N = c->N, mu = c->mu, m = c->m;
     // weights and mueff, lmcma.cpp:144-156
     std::vector<double> w(mu);
@@ -708,8 +771,21 @@ int lmcma_hip_opt_init(lmcma_hip_ctx *c, const double *xmean0, double sigma0)
     HIP_TRY(hipMemset(c->iterator, 0, m * sizeof(int32_t)));
     SampleScalars sc{(float)sigma0, 1.0f, 0, 0u};
     HIP_TRY(hipMemcpy(c->sc, &sc, sizeof(sc), hipMemcpyHostToDevice));
+    if (!c->xmean0) HIP_TRY(dalloc(&c->xmean0, (size_t)N));
+    HIP_TRY(hipMemcpy(c->xmean0, xmean0, N * sizeof(double), hipMemcpyHostToDevice));
+    c->sigma0 = sigma0;
     c->opt_ready = true;
     c->have_state = true;
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_opt_reset(lmcma_hip_ctx *c)
+{
+    CTX_TRY(c);
+    if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
+    hipLaunchKernelGGL(k_opt_reset, dim3(1), dim3(256), 0, c->stream, c->opt, c->sc, c->xmean0, c->sigma0,
+                       c->xmean, c->xmean_f, c->pc, c->N, c->ld);
+    HIP_TRY(hipGetLastError());
     return LMCMA_HIP_OK;
 }
 
@@ -724,12 +800,18 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
     if (n_generations < 0) return fail(LMCMA_HIP_ERR_ARG, "negative generation count");
     int left = n_generations;
     const bool use_graph = !c->timing && getenv("LMCMA_HIP_NO_GRAPH") == nullptr;
-    if (use_graph && left >= kGensPerGraph) {
+    while (use_graph && left >= kGensPerGraph) {
         if (!c->graph_exec) {
-            // one eager generation first: module load and LDS attribute calls stay out of the capture
-            int rc = one_generation(c);
-            if (rc != LMCMA_HIP_OK) return rc;
-            --left;
+            if (!c->warmed) {
+                // one eager generation first: module load and LDS attribute calls stay out of the capture
+                int rc = one_generation(c);
+                if (rc != LMCMA_HIP_OK) return rc;
+                --left;
+                c->warmed = true;
+                continue;
+            }
+            static_assert(kGensPerGraph % 2 == 0, "the sorted-cost buffers alternate per generation");
+            c->graph_parity = c->parity;
             HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             int crc = LMCMA_HIP_OK;
             for (int g = 0; g < kGensPerGraph && crc == LMCMA_HIP_OK; ++g) crc = one_generation(c);
@@ -738,11 +820,17 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
             if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
             e = hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0);
             if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+            // the capture only recorded the launches: none of the generations has run
         }
-        while (left >= kGensPerGraph) {
-            HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
-            left -= kGensPerGraph;
+        if (c->parity != c->graph_parity) {
+            // the graph was recorded starting from the other sorted-cost buffer: step once eagerly
+            int rc = one_generation(c);
+            if (rc != LMCMA_HIP_OK) return rc;
+            --left;
+            continue;
         }
+        HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+        left -= kGensPerGraph;
     }
     for (; left > 0; --left) {
         int rc = one_generation(c);
@@ -757,6 +845,7 @@ int lmcma_hip_phase_local(lmcma_hip_ctx *c)
     if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
     if (!c->grid) return fail(LMCMA_HIP_ERR_STATE, "set_grid must come first");
     if (c->cfg.z_source != LMCMA_Z_PHILOX) return fail(LMCMA_HIP_ERR_STATE, "phases need z_source PHILOX");
+    if (c->fused) return do_generate(c);
     int rc = do_sample(c, nullptr);
     if (rc != LMCMA_HIP_OK) return rc;
     return do_evaluate(c);
@@ -768,7 +857,7 @@ int lmcma_hip_phase_rank(lmcma_hip_ctx *c)
     if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
     int rc = do_select(c);
     if (rc != LMCMA_HIP_OK) return rc;
-    return do_recombine(c);
+    return do_recombine(c, true);
 }
 
 int lmcma_hip_phase_update(lmcma_hip_ctx *c, int n_partials)

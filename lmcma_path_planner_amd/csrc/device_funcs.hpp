@@ -1,0 +1,166 @@
+// Device functions shared by the sampling, cost and fused generation kernels.
+#pragma once
+
+#include "device_types.hpp"
+
+namespace lmcma {
+
+// ---- counter-based normals ---------------------------------------------------------
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Four standard normals for element quad `chunk` of (generation, candidate):
+// counter (chunk, candidate, generation, 0), key = seed; two Box-Muller transforms
+// on u = ((r >> 9) + 0.5) 2^-23 in (0,1), which fp32 holds exactly.
+__device__ __forceinline__ float4 philox_normals(uint32_t chunk, uint32_t candidate,
+                                                 uint32_t generation, uint32_t k0, uint32_t k1)
+{
+    uint32_t r[4];
+    philox4x32_10(chunk, candidate, generation, 0u, k0, k1, r);
+    const float scale = 1.0f / 8388608.0f;
+    const float u1a = ((float)(r[0] >> 9) + 0.5f) * scale;
+    const float u2a = ((float)(r[1] >> 9) + 0.5f) * scale;
+    const float u1b = ((float)(r[2] >> 9) + 0.5f) * scale;
+    const float u2b = ((float)(r[3] >> 9) + 0.5f) * scale;
+    const float ra = sqrtf(-2.0f * logf(u1a));
+    const float rb = sqrtf(-2.0f * logf(u1b));
+    float sa, ca, sb, cb;
+    sincospif(2.0f * u2a, &sa, &ca);
+    sincospif(2.0f * u2b, &sb, &cb);
+    return make_float4(ra * ca, ra * sa, rb * cb, rb * sb);
+}
+
+// ---- cross-lane sums ----------------------------------------------------------------
+// DPP moves data between lanes of a 16-lane row inside the VALU (no LDS round trip):
+// row_ror:n rotates a row by n lanes, quad_perm permutes within groups of four.
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Sum over each aligned row of 16 lanes, result in all 16.  Steps: rotate by 8, by 4,
+// swap pairs of pairs, swap neighbours.  At every step the lanes that end up with the
+// same set of terms add the same two values (in either order), so all 16 lanes hold
+// identical bits at the end.
+template <typename T>
+__device__ __forceinline__ T row16_sum(T v)
+{
+    v += dpp_mov<0x128>(v);  // row_ror:8
+    v += dpp_mov<0x124>(v);  // row_ror:4
+    v += dpp_mov<0x4E>(v);   // quad_perm:[2,3,0,1]
+    v += dpp_mov<0xB1>(v);   // quad_perm:[1,0,3,2]
+    return v;
+}
+
+// sum over groups of G consecutive lanes (G = 16, 32 or 64), identical bits in every lane
+template <int G>
+__device__ __forceinline__ float group_sum(float v)
+{
+    v = row16_sum(v);
+    if (G >= 32) v += __shfl_xor(v, 16, 64);
+    if (G >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// ---- trajectory cost ---------------------------------------------------------------
+
+template <int D>
+__device__ __forceinline__ float grid_value(const CostParams &p, const uint32_t *bits, const float *q)
+{
+    // clamp in float first: a NaN coordinate falls to cell 0, huge values saturate;
+    // rintf rounds half to even like nearbyint
+    const int ix = (int)rintf(fminf(fmaxf(q[0], 0.f), (float)(p.nx - 1)));
+    const int iy = (D > 1) ? (int)rintf(fminf(fmaxf(q[1], 0.f), (float)(p.ny - 1))) : 0;
+    const int iz = (D > 2) ? (int)rintf(fminf(fmaxf(q[2], 0.f), (float)(p.nz - 1))) : 0;
+    const int cell = (iz * p.ny + iy) * p.nx + ix;
+    if (p.grid_type == LMCMA_GRID_BITS)
+        return ((bits[cell >> 5] >> (cell & 31)) & 1u) ? p.c_obs : 0.f;
+    return reinterpret_cast<const float *>(p.grid)[cell];
+}
+
+// Contribution of waypoint k of `row` (dimension-major, W per dimension) to the
+// three cost terms.  The trapezoid grid integral is regrouped per node:
+// 1/2 c(node) (len_prev + len_next), with the fixed endpoints' shares added at the
+// first and last waypoint.
+template <int D>
+__device__ __forceinline__ void waypoint_terms(const CostParams &p, const uint32_t *bits,
+                                               const float *row, int k, float &j_len, float &j_grid,
+                                               float &j_smooth)
+{
+    constexpr float c_far = -1.0f / 12.0f, c_near = 16.0f / 12.0f;
+    const int W = p.W;
+    float q0[D];
+    float len_prev2 = 0.f, len_next2 = 0.f, acc2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float *r = row + d * W;
+        const float v0 = r[k];
+        const float vm1 = (k >= 1) ? r[k - 1] : p.start[d];
+        const float vp1 = (k + 1 < W) ? r[k + 1] : p.goal[d];
+        float sm1 = vm1, sp1 = vp1;
+        float sm2 = (k >= 2) ? r[k - 2] : p.start[d];
+        float sp2 = (k + 2 < W) ? r[k + 2] : p.goal[d];
+        if (p.pad_zero) {
+            if (k < 1) sm1 = 0.f;
+            if (k < 2) sm2 = 0.f;
+            if (k + 1 >= W) sp1 = 0.f;
+            if (k + 2 >= W) sp2 = 0.f;
+        }
+        q0[d] = v0;
+        const float dm = v0 - vm1, dp = vp1 - v0;
+        len_prev2 = fmaf(dm, dm, len_prev2);
+        len_next2 = fmaf(dp, dp, len_next2);
+        // -1/12 s[k-2] + 16/12 s[k-1] - 30/12 s[k] + 16/12 s[k+1] - 1/12 s[k+2],
+        // written on differences to s[k] (the five weights sum to zero)
+        const float a = fmaf(c_far, (sm2 - v0) + (sp2 - v0), c_near * ((sm1 - v0) + (sp1 - v0)));
+        acc2 = fmaf(a, a, acc2);
+    }
+    const float len_prev = sqrtf(len_prev2);
+    const float len_next = sqrtf(len_next2);
+    const float cv = grid_value<D>(p, bits, q0);
+    float gl = cv * (0.5f * (len_prev + len_next));
+    float ll = len_next;
+    if (k == 0) {
+        ll += len_prev;
+        gl = fmaf(p.c_start, 0.5f * len_prev, gl);
+    }
+    if (k == W - 1) gl = fmaf(p.c_goal, 0.5f * len_next, gl);
+    j_len += ll;
+    j_grid += gl;
+    j_smooth += acc2;
+}
+
+// weighted total, the three terms added left to right; NaN ranks last
+__device__ __forceinline__ float total_cost(const CostParams &p, float j_len, float j_grid, float j_smooth)
+{
+    float total = fmaf(p.w_smooth, j_smooth, fmaf(p.w_grid, j_grid, p.w_len * j_len));
+    if (total != total) total = __builtin_inff();
+    return total;
+}
+
+}  // namespace lmcma

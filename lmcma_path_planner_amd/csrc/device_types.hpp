@@ -49,7 +49,18 @@ struct CostParams {
     int grid_words;      // uint32 words of a bit grid (0 when not staged)
 };
 
+struct GenParams {
+    float *rows;              // [n_local][ld], written
+    const float *xmean, *V, *B, *lo, *hi;
+    const SampleScalars *sc;
+    int ld, n_local, m;
+    uint32_t first_candidate, key0, key1;
+    CostParams cost;          // cost.rows is not used: the rows come from LDS
+};
+
 // ---- launchers (each in the .hip file that defines its kernels) -------------
+hipError_t launch_generate(hipStream_t s, const GenParams &g, int dims, bool lds_grid);
+
 hipError_t launch_sample(hipStream_t s, float *rows, const float *zbuf, const float *xmean,
                          const float *V, const float *B, const float *lo, const float *hi,
                          const SampleScalars *sc, int ld, int n_local, uint32_t first_candidate,
@@ -59,10 +70,15 @@ hipError_t launch_sample(hipStream_t s, float *rows, const float *zbuf, const fl
 hipError_t launch_cost(hipStream_t s, const CostParams &p, int dims, bool lds_grid);
 
 constexpr int kSortTile = 4096;
+constexpr int kRankCountMax = 16384;  // populations up to this size are ranked by counting
 int select_num_tiles(int lambda);
-// keys_ws: uint64 [num_tiles * kSortTile]
+size_t select_workspace_bytes(int lambda);
+// keys_ws: select_workspace_bytes(lambda) bytes.  When opt != nullptr and opt->itr > 0 the
+// kernels also add, for every candidate, the number of entries of prev_sorted (last
+// generation's ascending costs) below its cost into *psr_accum (population success rule).
 hipError_t launch_select(hipStream_t s, const float *cost_all, int lambda, uint64_t *keys_ws,
-                         float *sorted_cost, int32_t *perm);
+                         float *sorted_cost, int32_t *perm, const OptScalars *opt,
+                         const float *prev_sorted, unsigned long long *psr_accum);
 
 constexpr int kRecombineRanksPerBlock = 32;
 int recombine_num_blocks(int mu);
@@ -77,7 +93,8 @@ struct UpdateArgs {
     const double *partials;  // [n_partials][N]
     int n_partials;
     const float *sorted_cost;   // [lambda] this generation, ascending
-    float *prev_sorted_cost;    // [lambda]
+    unsigned long long *psr_accum;  // sum over this generation's candidates of #{previous costs below it},
+                                    // left by the ranking kernels; read and zeroed by the update
     double *xmean, *pc;         // [N]
     double *pc_arr, *v_arr;     // [m][N]
     double *nj, *lj;            // [m]

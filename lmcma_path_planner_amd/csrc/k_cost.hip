@@ -24,33 +24,11 @@
 // shares at the first and last waypoint.  Rows are staged through LDS with
 // coalesced 16-byte loads so the +-2 neighbour reads are conflict-free LDS
 // reads; a bit-packed occupancy grid can be staged beside them.
-#include "device_types.hpp"
+#include "device_funcs.hpp"
 
 namespace lmcma {
 
 namespace {
-
-template <int G>
-__device__ __forceinline__ float group_sum(float v)
-{
-#pragma unroll
-    for (int s = G / 2; s >= 1; s >>= 1) v += __shfl_xor(v, s, G);
-    return v;
-}
-
-template <int D>
-__device__ __forceinline__ float grid_value(const CostParams &p, const uint32_t *bits,
-                                            const float *q)
-{
-    // clamp in float first: a NaN coordinate falls to cell 0, huge values saturate
-    const int ix = (int)rintf(fminf(fmaxf(q[0], 0.f), (float)(p.nx - 1)));
-    const int iy = (D > 1) ? (int)rintf(fminf(fmaxf(q[1], 0.f), (float)(p.ny - 1))) : 0;
-    const int iz = (D > 2) ? (int)rintf(fminf(fmaxf(q[2], 0.f), (float)(p.nz - 1))) : 0;
-    const int cell = (iz * p.ny + iy) * p.nx + ix;
-    if (p.grid_type == LMCMA_GRID_BITS)
-        return ((bits[cell >> 5] >> (cell & 31)) & 1u) ? p.c_obs : 0.f;
-    return reinterpret_cast<const float *>(p.grid)[cell];
-}
 
 template <int G, int D, bool GRID_LDS>
 __global__ __launch_bounds__(256) void k_cost(const CostParams p)
@@ -74,7 +52,6 @@ __global__ __launch_bounds__(256) void k_cost(const CostParams p)
     const int g = threadIdx.x / G;
     const int lane = threadIdx.x % G;
     const int ntiles = (p.n_rows + C - 1) / C;
-    constexpr float c_far = -1.0f / 12.0f, c_near = 16.0f / 12.0f;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C;
@@ -91,57 +68,13 @@ __global__ __launch_bounds__(256) void k_cost(const CostParams p)
         float j_len = 0.f, j_grid = 0.f, j_smooth = 0.f;
         if (g < nrows) {
             const float *row = srows + g * ld;
-            for (int k = lane; k < W; k += G) {
-                float q0[D], qm[D], qp[D];
-                float len_prev2 = 0.f, len_next2 = 0.f, acc2 = 0.f;
-#pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    const float *r = row + d * W;
-                    const float v0 = r[k];
-                    const float vm1 = (k >= 1) ? r[k - 1] : p.start[d];
-                    const float vp1 = (k + 1 < W) ? r[k + 1] : p.goal[d];
-                    float sm1 = vm1, sp1 = vp1;
-                    float sm2 = (k >= 2) ? r[k - 2] : p.start[d];
-                    float sp2 = (k + 2 < W) ? r[k + 2] : p.goal[d];
-                    if (p.pad_zero) {
-                        if (k < 1) sm1 = 0.f;
-                        if (k < 2) sm2 = 0.f;
-                        if (k + 1 >= W) sp1 = 0.f;
-                        if (k + 2 >= W) sp2 = 0.f;
-                    }
-                    q0[d] = v0; qm[d] = vm1; qp[d] = vp1;
-                    const float dm = v0 - vm1, dp = vp1 - v0;
-                    len_prev2 = fmaf(dm, dm, len_prev2);
-                    len_next2 = fmaf(dp, dp, len_next2);
-                    // -1/12 s[k-2] + 16/12 s[k-1] - 30/12 s[k] + 16/12 s[k+1] - 1/12 s[k+2],
-                    // written on differences to s[k] (the five weights sum to zero)
-                    const float a = fmaf(c_far, (sm2 - v0) + (sp2 - v0), c_near * ((sm1 - v0) + (sp1 - v0)));
-                    acc2 = fmaf(a, a, acc2);
-                }
-                (void)qm; (void)qp;
-                const float len_prev = sqrtf(len_prev2);
-                const float len_next = sqrtf(len_next2);
-                const float cv = grid_value<D>(p, bits, q0);
-                float gl = cv * (0.5f * (len_prev + len_next));
-                float ll = len_next;
-                if (k == 0) {
-                    ll += len_prev;
-                    gl = fmaf(p.c_start, 0.5f * len_prev, gl);
-                }
-                if (k == W - 1) gl = fmaf(p.c_goal, 0.5f * len_next, gl);
-                j_len += ll;
-                j_grid += gl;
-                j_smooth += acc2;
-            }
+            for (int k = lane; k < W; k += G) waypoint_terms<D>(p, bits, row, k, j_len, j_grid, j_smooth);
         }
         j_len = group_sum<G>(j_len);
         j_grid = group_sum<G>(j_grid);
         j_smooth = group_sum<G>(j_smooth);
         if (g < nrows && lane == 0) {
-            float total = p.w_len * j_len;
-            total += p.w_grid * j_grid;
-            total += p.w_smooth * j_smooth;
-            if (total != total) total = __builtin_inff();  // NaN ranks last
+            const float total = total_cost(p, j_len, j_grid, j_smooth);
             p.cost[row0 + g] = total;
             if (p.terms) {
                 float *t = p.terms + 3 * (size_t)(row0 + g);

@@ -1,0 +1,218 @@
+// Fused generation kernel: draw a candidate and score it in one launch.
+//
+// The sampling half is LMCMA::sample / computeAz / applyBoundaries
+// (lmcma_path_planner/src/lmcma.cpp:301-311, 431-447, 220-230), the scoring half the
+// trajectory cost described in k_cost.hip; both halves use the same device
+// functions as the separate kernels, so a fused launch produces the same bits.
+//
+// 32 lanes own one candidate through both halves.  In the sampling half lane l owns
+// the float4 chunks l, l+32, ... of the row (Philox normals, the k dot products
+// reduced over the 32 lanes, the rank-one updates, clamping); the finished row goes
+// to global memory (the recombination reads it) and to LDS.  In the scoring half
+// lane l owns waypoints l, l+32, ... and reads its +-2 neighbours from the LDS copy,
+// so the row never comes back from HBM.  The direction vectors (V, B) are staged in
+// LDS once per block when they fit, and a bit-packed occupancy grid can be staged
+// beside them; blocks walk several candidate tiles to amortise that staging.
+#include "device_funcs.hpp"
+
+namespace lmcma {
+
+namespace {
+
+constexpr int kLanes = 32;           // lanes per candidate
+constexpr int kTile = 256 / kLanes;  // candidates per block pass
+
+// J = float4 chunks per lane (row stride <= 128 J floats)
+template <int J, int D, bool GRID_LDS, bool VB_LDS>
+__global__ __launch_bounds__(256) void k_generate(const GenParams g)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const CostParams &p = g.cost;
+    const int ld = g.ld;
+    const int nchunks = ld >> 2;
+    const int k = g.sc->k;
+    const float sigma = g.sc->sigma;
+    const float mk = g.sc->mk;
+    const uint32_t generation = g.sc->generation;
+
+    float *srows = smem;                       // [kTile][ld]
+    float *sV = srows + kTile * ld;            // [m][ld] when VB_LDS
+    float *sB = sV + (VB_LDS ? g.m * ld : 0);  // [m][ld] when VB_LDS
+    uint32_t *sbits = reinterpret_cast<uint32_t *>(sB + (VB_LDS ? g.m * ld : 0));
+
+    if (VB_LDS) {
+        const int n4 = (k * ld) >> 2;
+        const float4 *srcV = reinterpret_cast<const float4 *>(g.V);
+        const float4 *srcB = reinterpret_cast<const float4 *>(g.B);
+        float4 *dstV = reinterpret_cast<float4 *>(sV), *dstB = reinterpret_cast<float4 *>(sB);
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            dstV[i] = srcV[i];
+            dstB[i] = srcB[i];
+        }
+    }
+    const uint32_t *bits;
+    if (GRID_LDS) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.grid);
+        uint4 *dst = reinterpret_cast<uint4 *>(sbits);
+        for (int i = threadIdx.x; i < (p.grid_words >> 2); i += 256) dst[i] = src[i];
+        bits = sbits;
+    } else {
+        bits = reinterpret_cast<const uint32_t *>(p.grid);
+    }
+    const float *Vp = VB_LDS ? sV : g.V;
+    const float *Bp = VB_LDS ? sB : g.B;
+
+    const int lane = threadIdx.x & (kLanes - 1);
+    const int slot = threadIdx.x / kLanes;
+    const int ntiles = (g.n_local + kTile - 1) / kTile;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int cand = tile * kTile + slot;
+        const bool live = cand < g.n_local;
+        const int c = live ? cand : g.n_local - 1;  // idle groups shadow the last row (shuffles need all lanes)
+
+        // ---- sample --------------------------------------------------------------------
+        float4 z[J], acc[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int chunk = j * kLanes + lane;
+            z[j] = (chunk < nchunks) ? philox_normals((uint32_t)chunk, g.first_candidate + (uint32_t)c,
+                                                      generation, g.key0, g.key1)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc[j] = make_float4(mk * z[j].x, mk * z[j].y, mk * z[j].z, mk * z[j].w);
+        }
+        __syncthreads();  // staging done (first pass) / previous tile's rows consumed (later passes)
+
+        for (int t = 0; t < k; ++t) {
+            const float4 *v = reinterpret_cast<const float4 *>(Vp + (size_t)t * ld);
+            const float4 *b = reinterpret_cast<const float4 *>(Bp + (size_t)t * ld);
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int chunk = j * kLanes + lane;
+                if (chunk < nchunks) {
+                    const float4 vv = v[chunk];
+                    d = fmaf(vv.x, z[j].x, d);
+                    d = fmaf(vv.y, z[j].y, d);
+                    d = fmaf(vv.z, z[j].z, d);
+                    d = fmaf(vv.w, z[j].w, d);
+                }
+            }
+            d = group_sum<kLanes>(d);
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int chunk = j * kLanes + lane;
+                if (chunk < nchunks) {
+                    const float4 bb = b[chunk];
+                    acc[j].x = fmaf(d, bb.x, acc[j].x);
+                    acc[j].y = fmaf(d, bb.y, acc[j].y);
+                    acc[j].z = fmaf(d, bb.z, acc[j].z);
+                    acc[j].w = fmaf(d, bb.w, acc[j].w);
+                }
+            }
+        }
+
+        float4 *out = reinterpret_cast<float4 *>(g.rows + (size_t)c * ld);
+        float4 *lrow = reinterpret_cast<float4 *>(srows + slot * ld);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int chunk = j * kLanes + lane;
+            if (chunk < nchunks) {
+                const float4 xm = reinterpret_cast<const float4 *>(g.xmean)[chunk];
+                const float4 l4 = reinterpret_cast<const float4 *>(g.lo)[chunk];
+                const float4 h4 = reinterpret_cast<const float4 *>(g.hi)[chunk];
+                float4 x;
+                // max with the lower bound first, then min with the upper one (lmcma.cpp:222-229)
+                x.x = fminf(fmaxf(fmaf(sigma, acc[j].x, xm.x), l4.x), h4.x);
+                x.y = fminf(fmaxf(fmaf(sigma, acc[j].y, xm.y), l4.y), h4.y);
+                x.z = fminf(fmaxf(fmaf(sigma, acc[j].z, xm.z), l4.z), h4.z);
+                x.w = fminf(fmaxf(fmaf(sigma, acc[j].w, xm.w), l4.w), h4.w);
+                lrow[chunk] = x;
+                if (live) out[chunk] = x;
+            }
+        }
+        __syncthreads();  // the tile's rows are complete in LDS
+
+        // ---- score ---------------------------------------------------------------------
+        float j_len = 0.f, j_grid = 0.f, j_smooth = 0.f;
+        const float *row = srows + slot * ld;
+        for (int w = lane; w < p.W; w += kLanes) waypoint_terms<D>(p, bits, row, w, j_len, j_grid, j_smooth);
+        j_len = group_sum<kLanes>(j_len);
+        j_grid = group_sum<kLanes>(j_grid);
+        j_smooth = group_sum<kLanes>(j_smooth);
+        if (live && lane == 0) {
+            p.cost[cand] = total_cost(p, j_len, j_grid, j_smooth);
+            if (p.terms) {
+                float *t = p.terms + 3 * (size_t)cand;
+                t[0] = j_len; t[1] = j_grid; t[2] = j_smooth;
+            }
+        }
+    }
+}
+
+template <int J, int D, bool GRID_LDS, bool VB_LDS>
+hipError_t launch_t(hipStream_t s, const GenParams &g, size_t lds, int blocks)
+{
+    static size_t configured = 48 * 1024;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_generate<J, D, GRID_LDS, VB_LDS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL((k_generate<J, D, GRID_LDS, VB_LDS>), dim3(blocks), dim3(256), lds, s, g);
+    return hipGetLastError();
+}
+
+template <int J, int D>
+hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds)
+{
+    const int ntiles = (g.n_local + kTile - 1) / kTile;
+    const size_t rows_b = (size_t)kTile * g.ld * sizeof(float);
+    const size_t vb_b = 2 * (size_t)g.m * g.ld * sizeof(float);
+    const size_t grid_b = grid_lds ? (size_t)g.cost.grid_words * sizeof(uint32_t) : 0;
+    const size_t budget = 160 * 1024;
+    const bool vb_lds = rows_b + vb_b + grid_b <= budget && g.m <= 32;
+    if (grid_lds && rows_b + (vb_lds ? vb_b : 0) + grid_b > budget) grid_lds = false;
+    const size_t lds = rows_b + (vb_lds ? vb_b : 0) + (grid_lds ? grid_b : 0);
+    // staging is paid per block: one block per CU when something is staged and there
+    // are enough tiles, otherwise one block per tile up to eight blocks per CU
+    const int blocks = (grid_lds || vb_lds) ? (ntiles < 512 ? ntiles : (grid_lds ? 256 : 512))
+                                            : (ntiles < 2048 ? ntiles : 2048);
+    if (grid_lds) {
+        if (vb_lds) return launch_t<J, D, true, true>(s, g, lds, blocks);
+        return launch_t<J, D, true, false>(s, g, lds, blocks);
+    }
+    if (vb_lds) return launch_t<J, D, false, true>(s, g, lds, blocks);
+    return launch_t<J, D, false, false>(s, g, lds, blocks);
+}
+
+template <int D>
+hipError_t launch_d(hipStream_t s, const GenParams &g, bool grid_lds)
+{
+    switch ((g.ld + 127) / 128) {
+        case 1: return launch_jd<1, D>(s, g, grid_lds);
+        case 2: return launch_jd<2, D>(s, g, grid_lds);
+        case 3: return launch_jd<3, D>(s, g, grid_lds);
+        case 4: return launch_jd<4, D>(s, g, grid_lds);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_generate(hipStream_t s, const GenParams &g, int dims, bool grid_lds)
+{
+    if (g.n_local <= 0) return hipSuccess;
+    if (g.ld <= 0 || (g.ld & 3) || g.ld > 512 || g.cost.W < 1 || dims * g.cost.W > g.ld)
+        return hipErrorInvalidValue;
+    if (grid_lds && (g.cost.grid_type != LMCMA_GRID_BITS || (g.cost.grid_words & 3))) return hipErrorInvalidValue;
+    switch (dims) {
+        case 1: return launch_d<1>(s, g, grid_lds);
+        case 2: return launch_d<2>(s, g, grid_lds);
+        case 3: return launch_d<3>(s, g, grid_lds);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace lmcma

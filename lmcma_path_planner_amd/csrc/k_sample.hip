@@ -12,56 +12,11 @@
 // bytes per step and the four groups of a wave64 share the same V/B cache lines.
 // The k dot products are reduced over the 16 lanes with an xor butterfly, which
 // leaves bit-identical sums in every lane of the group.
-#include "device_types.hpp"
+#include "device_funcs.hpp"
 
 namespace lmcma {
 
 namespace {
-
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4])
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0;
-        const uint32_t n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-// Four standard normals for element quad `chunk` of (generation, candidate):
-// two Box-Muller transforms on u = ((r >> 8) + 0.5) 2^-24 in (0,1).
-__device__ __forceinline__ float4 philox_normals(uint32_t chunk, uint32_t candidate,
-                                                 uint32_t generation, uint32_t k0, uint32_t k1)
-{
-    uint32_t r[4];
-    philox4x32_10(chunk, candidate, generation, 0u, k0, k1, r);
-    const float scale = 1.0f / 16777216.0f;
-    const float u1a = ((float)(r[0] >> 8) + 0.5f) * scale;
-    const float u2a = ((float)(r[1] >> 8) + 0.5f) * scale;
-    const float u1b = ((float)(r[2] >> 8) + 0.5f) * scale;
-    const float u2b = ((float)(r[3] >> 8) + 0.5f) * scale;
-    const float ra = sqrtf(-2.0f * logf(u1a));
-    const float rb = sqrtf(-2.0f * logf(u1b));
-    float sa, ca, sb, cb;
-    sincospif(2.0f * u2a, &sa, &ca);
-    sincospif(2.0f * u2b, &sb, &cb);
-    return make_float4(ra * ca, ra * sa, rb * cb, rb * sb);
-}
-
-__device__ __forceinline__ float group16_sum(float v)
-{
-    v += __shfl_xor(v, 8, 16);
-    v += __shfl_xor(v, 4, 16);
-    v += __shfl_xor(v, 2, 16);
-    v += __shfl_xor(v, 1, 16);
-    return v;
-}
 
 // J = float4 chunks per lane; the row stride ld (a multiple of 4) must be <= 64 J.
 template <int J>
@@ -117,7 +72,7 @@ __global__ __launch_bounds__(256) void k_sample(float *__restrict__ rows,
                 d = fmaf(vv.w, z[j].w, d);
             }
         }
-        d = group16_sum(d);
+        d = group_sum<16>(d);
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int chunk = j * 16 + lane;

@@ -2,96 +2,159 @@
 //
 // Replaces LMCMA::update (lmcma_path_planner/src/lmcma.cpp:313-424) and invAz
 // (:449-463); the citations L/:a-b below are lines of that file.
-#include "device_types.hpp"
+#include "device_funcs.hpp"
 
 namespace lmcma {
 
 namespace {
 
 // ---- weighted recombination, L/:321-326 --------------------------------------
-// Block b sums ranks [32 b, 32 b + 32) of the elite list in rank order, one
-// thread per coordinate (coalesced row reads); rows that live in another
-// context are skipped.  k_recombine_final adds the block partials in block
-// order, so the result does not depend on scheduling.
+// Block b owns ranks [32 b, 32 b + 32) of the elite list.  A thread owns one
+// float4 column chunk of one "slot"; slot s walks ranks s, s + nslots, ... of the
+// block in order, so all row loads of a block are independent and coalesced.
+// The slots are then added in slot order through LDS, and k_update (or
+// k_recombine_final) adds the blocks in block order: the summation tree is fixed
+// by (mu, ld) alone.  Rows that live in another context are skipped.
 __global__ __launch_bounds__(256) void k_recombine_partial(const float *__restrict__ rows, int ld,
                                                            int N, int first_candidate, int n_local,
                                                            const int32_t *__restrict__ perm,
                                                            const double *__restrict__ weights,
                                                            int mu, double *__restrict__ block_partials)
 {
+    extern __shared__ __attribute__((aligned(16))) double s_part[];  // [nslots][ld]
+    const int nq = ld >> 2;               // float4 chunks per row (<= 128)
+    const int nslots = 256 / nq;
     const int r0 = blockIdx.x * kRecombineRanksPerBlock;
     const int r1 = min(mu, r0 + kRecombineRanksPerBlock);
+    const int slot = threadIdx.x / nq;
+    const int q = threadIdx.x % nq;
+    if (slot < nslots) {
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int r = r0 + slot; r < r1; r += nslots) {
+            const int local = perm[r] - first_candidate;
+            if (local >= 0 && local < n_local) {
+                const float4 x = reinterpret_cast<const float4 *>(rows + (size_t)local * ld)[q];
+                const double w = weights[r];
+                a0 += w * (double)x.x; a1 += w * (double)x.y;
+                a2 += w * (double)x.z; a3 += w * (double)x.w;
+            }
+        }
+        double *dst = s_part + (size_t)slot * ld + 4 * q;
+        dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
+    }
+    __syncthreads();
     for (int n = threadIdx.x; n < N; n += 256) {
         double acc = 0.0;
-        for (int r = r0; r < r1; ++r) {
-            const int local = perm[r] - first_candidate;
-            if (local >= 0 && local < n_local)
-                acc += weights[r] * (double)rows[(size_t)local * ld + n];
-        }
+        for (int s = 0; s < nslots; ++s) acc += s_part[(size_t)s * ld + n];
         block_partials[(size_t)blockIdx.x * N + n] = acc;
     }
+}
+
+// sum of `count` rows of src[count][N] in row order, 8 threads per coordinate:
+// thread j of a coordinate adds rows j, j+8, ...; the 8 partial sums are then
+// added in lane order 0..7 (fixed tree).
+__device__ __forceinline__ double strided_sum8(const double *__restrict__ src, int count, int N, int n, int j)
+{
+    double acc = 0.0;
+    for (int b0 = j; b0 < count; b0 += 64) {
+        // eight independent loads in flight, then added in row order
+        double r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = b0 + 8 * u;
+            r[u] = b < count ? src[(size_t)b * N + n] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (b0 + 8 * u < count) acc += r[u];
+    }
+    // lanes j = 0..7 are consecutive lanes of one wave
+    double total = 0.0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) total += __shfl(acc, (threadIdx.x & 56) + s, 64);
+    return total;
 }
 
 __global__ __launch_bounds__(256) void k_recombine_final(const double *__restrict__ block_partials,
                                                          int nblocks, int N,
                                                          double *__restrict__ partial_local)
 {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    double acc = 0.0;
-    for (int b = 0; b < nblocks; ++b) acc += block_partials[(size_t)b * N + n];
-    partial_local[n] = acc;
+    const int n = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int j = threadIdx.x & 7;
+    const int nn = n < N ? n : N - 1;  // idle lanes shadow a valid column (shuffles need all lanes)
+    const double total = strided_sum8(block_partials, nblocks, N, nn, j);
+    if (n < N && j == 0) partial_local[n] = total;
 }
 
 // ---- update ---------------------------------------------------------------------
-
-__device__ __forceinline__ double wave_sum(double v)
+//
+// One workgroup; 16 lanes own one direction vector, EMAX coordinates per lane held
+// in registers.  V_LDS: finished vectors are published through LDS (m * N * 8
+// bytes), otherwise through their home rows in global memory.  Global stores are
+// kept out of the loop (a workgroup barrier waits for outstanding stores) and issued
+// once at the end.
+template <int EMAX, bool V_LDS>
+__global__ __launch_bounds__(1024) void k_update(const UpdateArgs a)
 {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
-    return v;
-}
-
-__device__ __forceinline__ double wave_dot(const double *a, const double *b, int N, int lane)
-{
-    double d = 0.0;
-    for (int n = lane; n < N; n += 64) d += a[n] * b[n];
-    return wave_sum(d);
-}
-
-constexpr int kUpdThreads = 1024;
-
-__global__ __launch_bounds__(kUpdThreads) void k_update(const UpdateArgs a)
-{
-    __shared__ int s_t[LMCMA_HIP_MAX_VECTORS];
-    __shared__ int s_imin, s_isz, s_newidx;
-    __shared__ long long s_rank_part[kUpdThreads / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int nwaves = kUpdThreads / 64;
+    // all LDS in one dynamic array, widest elements first, so every carve stays aligned
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+    const int T = blockDim.x;
+    const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4;
     const int N = a.N, m = a.m, lambda = a.lambda;
     OptScalars &o = *a.opt;
     const double sigma = o.sigma, cc = o.cc, c1 = o.c1;
     const int itr = o.itr;
 
-    // L/:316-329: new mean from the rank-ordered partial sums, evolution path
-    const double pc_gain = sqrt(cc * (2 - cc) * o.mueff);
-    for (int n = tid; n < N; n += kUpdThreads) {
-        double xnew = 0.0;
-        for (int p = 0; p < a.n_partials; ++p) xnew += a.partials[(size_t)p * N + n];
-        const double xold = a.xmean[n];
-        a.xmean[n] = xnew;
-        a.pc[n] = (1 - cc) * a.pc[n] + pc_gain * (xnew - xold) / sigma;
+    double *s_v = s_dyn;                                        // [m][N] when V_LDS
+    double *s_pc = s_dyn + (V_LDS ? (size_t)m * N : 0);         // [N] new evolution path
+    double *s_xm = s_pc + N;                                    // [N] new mean
+    double *s_lj = s_xm + N;                                    // [64], slot-indexed
+    double *s_nj = s_lj + LMCMA_HIP_MAX_VECTORS;                // [64], slot-indexed
+    int *s_t = reinterpret_cast<int *>(s_nj + LMCMA_HIP_MAX_VECTORS);  // [64]
+    int *s_vec = s_t + LMCMA_HIP_MAX_VECTORS;                   // [64]
+    int *s_misc = s_vec + LMCMA_HIP_MAX_VECTORS;                // imin, isz, newidx
+    int &s_imin = s_misc[0], &s_isz = s_misc[1], &s_newidx = s_misc[2];
+
+    if (tid < m) {
+        s_t[tid] = a.t[tid];
+        s_vec[tid] = a.vec[tid];
+        s_lj[tid] = a.lj[tid];
+        s_nj[tid] = a.nj[tid];
     }
+    // inputs of the step-size rule, fetched early (thread 0 uses them at the end)
+    unsigned long long psr_in = 0ull;
+    float best_in = 0.f;
+    if (tid == 0) {
+        psr_in = *a.psr_accum;
+        best_in = a.sorted_cost[0];
+    }
+
+    // L/:316-329: new mean from the rank-ordered partial sums, evolution path.
+    // 8 threads per coordinate add the partials (see strided_sum8); thread 0 of each
+    // coordinate keeps the results in registers when one pass covers all coordinates.
+    const double pc_gain = sqrt(cc * (2 - cc) * o.mueff);
+    for (int n0 = 0; n0 < N; n0 += T / 8) {
+        const int n = n0 + (tid >> 3);
+        const int nn = n < N ? n : N - 1;
+        const double xnew = strided_sum8(a.partials, a.n_partials, N, nn, tid & 7);
+        if (n < N && (tid & 7) == 0) {
+            const double xold = a.xmean[n];
+            const double pcn = (1 - cc) * a.pc[n] + pc_gain * (xnew - xold) / sigma;
+            s_pc[n] = pcn;
+            s_xm[n] = xnew;
+        }
+    }
+    __syncthreads();
 
     // L/:331-364: which slot receives the new direction
     if (tid == 0) {
         int imin = 1;
         if (itr < m) {
-            a.t[itr] = itr;
+            s_t[itr] = itr;
         } else if (m > 1) {
-            int dmin = a.vec[a.t[1]] - a.vec[a.t[0]];
+            int dmin = s_vec[s_t[1]] - s_vec[s_t[0]];
             for (int j = 1; j < m - 1; ++j) {
-                const int dcur = a.vec[a.t[j + 1]] - a.vec[a.t[j]];
+                const int dcur = s_vec[s_t[j + 1]] - s_vec[s_t[j]];
                 if (dcur < dmin) {
                     dmin = dcur;
                     imin = j + 1;
@@ -99,21 +162,17 @@ __global__ __launch_bounds__(kUpdThreads) void k_update(const UpdateArgs a)
             }
             if (dmin >= m) imin = 0;  // maxsteps = nvectors (L/:267)
             if (imin != m - 1) {
-                const int sav = a.t[imin];
-                for (int j = imin; j < m - 1; ++j) a.t[j] = a.t[j + 1];
-                a.t[m - 1] = sav;
+                const int sav = s_t[imin];
+                for (int j = imin; j < m - 1; ++j) s_t[j] = s_t[j + 1];
+                s_t[m - 1] = sav;
             }
         } else {
             imin = 0;
         }
         int isz = itr + 1;
         if (isz > m) isz = m;
-        for (int i = 0; i < isz; ++i) {
-            a.iterator[i] = a.t[i];
-            s_t[i] = a.t[i];
-        }
-        const int newidx = a.t[isz - 1];
-        a.vec[newidx] = itr;
+        const int newidx = s_t[isz - 1];
+        s_vec[newidx] = itr;
         if (imin == 1) imin = 0;  // L/:373-374
         s_imin = imin;
         s_isz = isz;
@@ -122,72 +181,74 @@ __global__ __launch_bounds__(kUpdThreads) void k_update(const UpdateArgs a)
     __syncthreads();
     const int imin = s_imin, isz = s_isz, newidx = s_newidx;
 
-    // L/:365-366 and the start of the recomputation (:378-379): Av_i <- pc_arr[t[i]]
-    for (int n = tid; n < N; n += kUpdThreads) a.pc_arr[(size_t)newidx * N + n] = a.pc[n];
-    __syncthreads();
-    for (int i = imin + wave; i < isz; i += nwaves) {
-        const int slot = s_t[i];
-        for (int n = lane; n < N; n += 64)
-            a.v_arr[(size_t)slot * N + n] = a.pc_arr[(size_t)slot * N + n];
+    // L/:375-390 with invAz (:449-463).  Vector i is v_i = T_{i-1} ... T_0 pc_i with
+    // T_j = K I - lj_j v_j v_j^T.  The reference finishes vector i before it starts
+    // i+1; here j is the outer loop and every unfinished vector applies T_j at the same
+    // time (one 16-lane group per vector, the vector in registers), so each vector
+    // still sees exactly the reference's sequence of operations.  Vectors before imin
+    // keep last generation's value (L/:375 starts at imin).
+    const bool own = grp < isz;
+    const int slot = own ? s_t[grp] : 0;
+    const bool rebuild = own && grp >= imin;
+    double av[EMAX], pcq[EMAX];  // the vector and its evolution path pc_arr[slot]
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        const int n = e * 16 + lane;
+        const bool in = own && n < N;
+        // L/:365-366: the new evolution path enters the store at slot newidx
+        pcq[e] = in ? (slot == newidx ? s_pc[n] : a.pc_arr[(size_t)slot * N + n]) : 0.0;
+        av[e] = rebuild ? pcq[e] : (in ? a.v_arr[(size_t)slot * N + n] : 0.0);
+        if (V_LDS && in && !rebuild) s_v[(size_t)grp * N + n] = av[e];
     }
-    __syncthreads();
-
-    // L/:375-390 with invAz (:449-463).  The reference finishes vector i before it
-    // starts i+1; vector i only needs the transforms T_j = K I - lj_j v_j v_j^T of the
-    // vectors before it, applied in order j = 0..i-1.  Here j is the outer loop and
-    // every unfinished vector applies T_j at the same time (one wave per vector), so
-    // each vector still sees exactly the reference's sequence of operations.
     const double sq = sqrt(1 - c1), ratio = c1 / (1 - c1), K = o.K;
     for (int i = 0; i < isz; ++i) {
-        // vector i has received T_0..T_{i-1} and is final: publish its coefficients
-        if (i >= imin && ((i - imin) % nwaves) == wave) {
-            const int slot = s_t[i];
-            const double *v = a.v_arr + (size_t)slot * N;
-            const double nv = wave_dot(v, v, N, lane);
+        // vector i has received T_0..T_{i-1}: it is final, its owner publishes it
+        if (grp == i && rebuild) {
+            double nv = 0.0;
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) nv += av[e] * av[e];
+            nv = row16_sum(nv);
+            double *dst = V_LDS ? s_v + (size_t)i * N : a.v_arr + (size_t)slot * N;
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) {
+                const int n = e * 16 + lane;
+                if (n < N) dst[n] = av[e];
+            }
             if (lane == 0) {
-                a.nj[slot] = (sq / nv) * (sqrt(1 + ratio * nv) - 1);
-                a.lj[slot] = (1 / (sq * nv)) * (1 - (1 / sqrt(1 + ratio * nv)));
+                s_nj[slot] = (sq / nv) * (sqrt(1 + ratio * nv) - 1);
+                s_lj[slot] = (1 / (sq * nv)) * (1 - (1 / sqrt(1 + ratio * nv)));
             }
         }
         __syncthreads();
-        // apply T_i to every later vector that is being recomputed
-        const int slot_i = s_t[i];
-        const double *vi = a.v_arr + (size_t)slot_i * N;
-        const double lj = a.lj[slot_i];
-        for (int q = (i + 1 > imin) ? i + 1 : imin; q < isz; ++q) {
-            if (((q - imin) % nwaves) != wave) continue;
-            double *av = a.v_arr + (size_t)s_t[q] * N;
-            const double d = lj * wave_dot(vi, av, N, lane);
-            for (int n = lane; n < N; n += 64) av[n] = K * av[n] - d * vi[n];
+        // T_i on every later vector that is being rebuilt.  The next publication writes
+        // row i+1 and other coefficient words, so one barrier per step is enough.
+        if (rebuild && grp > i) {
+            const int slot_i = s_t[i];
+            const double *vi = V_LDS ? s_v + (size_t)i * N : a.v_arr + (size_t)slot_i * N;
+            double vv[EMAX];
+            double d = 0.0;
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) {
+                const int n = e * 16 + lane;
+                vv[e] = n < N ? vi[n] : 0.0;
+                d += vv[e] * av[e];
+            }
+            d = s_lj[slot_i] * row16_sum(d);
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) av[e] = K * av[e] - d * vv[e];
         }
-        __syncthreads();
     }
+    __syncthreads();
 
     // L/:393-419: population success rule.  In the merged stable sort of
     // [current | previous] an element of the current generation at sorted position i
-    // gets rank i + #{previous < it}; the reference's "meanprev" is the mean rank of
-    // the current generation and "meancur" that of the previous one.
-    if (itr > 0) {
-        long long part = 0;
-        for (int i = tid; i < lambda; i += kUpdThreads) {
-            const float c = a.sorted_cost[i];
-            int lo = 0, hi = lambda;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (a.prev_sorted_cost[mid] < c) lo = mid + 1; else hi = mid;
-            }
-            part += i + lo;
-        }
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) part += __shfl_xor(part, s, 64);
-        if (lane == 0) s_rank_part[wave] = part;
-    }
-    __syncthreads();
+    // gets rank i + #{previous < it}; the ranking kernels have summed the second term
+    // into psr_accum.  The reference's "meanprev" is the mean rank of the current
+    // generation and "meancur" that of the previous one.
     if (tid == 0) {
         double new_sigma = sigma;
         if (itr > 0) {
-            long long cur_sum = 0;
-            for (int w = 0; w < nwaves; ++w) cur_sum += s_rank_part[w];
+            const long long cur_sum = (long long)lambda * (lambda - 1) / 2 + (long long)psr_in;
             const long long total = (long long)lambda * (2ll * lambda - 1);  // sum of 0..2*lambda-1
             const double mean_current = (double)cur_sum / lambda;
             const double mean_previous = (double)(total - cur_sum) / lambda;
@@ -197,8 +258,9 @@ __global__ __launch_bounds__(kUpdThreads) void k_update(const UpdateArgs a)
             new_sigma = sigma * exp(o.s / 1.0);
             o.sigma = new_sigma;
         }
+        *a.psr_accum = 0ull;  // ready for the next generation's ranking
         // CMABase::setEvaluationFeedback bookkeeping, L/:191-198, for lambda candidates
-        const double best = (double)a.sorted_cost[0];
+        const double best = (double)best_in;
         if (best < o.best_f || o.counteval == 0) o.best_f = best;
         o.counteval += lambda;
         o.itr = itr + 1;
@@ -212,19 +274,38 @@ __global__ __launch_bounds__(kUpdThreads) void k_update(const UpdateArgs a)
         a.sc->k = isz;
         a.sc->generation = (uint32_t)(itr + 1);
     }
-    __syncthreads();  // the PSR reads of prev_sorted_cost are done
 
-    // L/:420-421 and the float images the sampling kernel reads
-    for (int i = tid; i < lambda; i += kUpdThreads) a.prev_sorted_cost[i] = a.sorted_cost[i];
-    for (int n = tid; n < a.ld; n += kUpdThreads) a.xmean_f[n] = (n < N) ? (float)a.xmean[n] : 0.f;
-    for (int q = wave; q < isz; q += nwaves) {
-        const int slot = s_t[q];
-        double coef = a.nj[slot];
-        for (int e = 0; e < isz - 1 - q; ++e) coef *= o.M;  // M^(k-1-t) nj
-        for (int n = lane; n < a.ld; n += 64) {
-            const bool in = n < N;
-            a.V_f[(size_t)q * a.ld + n] = in ? (float)a.v_arr[(size_t)slot * N + n] : 0.f;
-            a.B_f[(size_t)q * a.ld + n] = in ? (float)(coef * a.pc_arr[(size_t)slot * N + n]) : 0.f;
+    // state back to memory, and the float images the sampling kernel reads:
+    // V_f[q] = v_q, B_f[q] = M^(k-1-q) nj_q pc_q
+    for (int n = tid; n < a.ld; n += T) {
+        if (n < N) {
+            a.xmean[n] = s_xm[n];
+            a.pc[n] = s_pc[n];
+        }
+        a.xmean_f[n] = (n < N) ? (float)s_xm[n] : 0.f;
+    }
+    if (tid < m) {
+        a.t[tid] = s_t[tid];
+        a.vec[tid] = s_vec[tid];
+        a.nj[tid] = s_nj[tid];
+        a.lj[tid] = s_lj[tid];
+        if (tid < isz) a.iterator[tid] = s_t[tid];
+    }
+    if (own) {
+        double coef = s_nj[slot];
+        const double Mfac = o.M;
+        for (int e = 0; e < isz - 1 - grp; ++e) coef *= Mfac;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const int n = e * 16 + lane;
+            if (n < N) {
+                if (slot == newidx) a.pc_arr[(size_t)slot * N + n] = pcq[e];
+                if (rebuild && V_LDS) a.v_arr[(size_t)slot * N + n] = av[e];
+            }
+            if (n < a.ld) {
+                a.V_f[(size_t)grp * a.ld + n] = (n < N) ? (float)av[e] : 0.f;
+                a.B_f[(size_t)grp * a.ld + n] = (n < N) ? (float)(coef * pcq[e]) : 0.f;
+            }
         }
     }
 }
@@ -240,23 +321,52 @@ hipError_t launch_recombine(hipStream_t s, const float *rows, int ld, int N, int
                             int n_local, const int32_t *perm, const double *weights, int mu,
                             double *block_partials, double *partial_local)
 {
-    if (mu <= 0 || N <= 0) return hipErrorInvalidValue;
+    if (mu <= 0 || N <= 0 || (ld & 3) || ld > 512) return hipErrorInvalidValue;
     const int nb = recombine_num_blocks(mu);
-    hipLaunchKernelGGL(k_recombine_partial, dim3(nb), dim3(256), 0, s, rows, ld, N, first_candidate,
+    const int nslots = 256 / (ld >> 2);
+    const size_t lds = (size_t)nslots * ld * sizeof(double);
+    hipLaunchKernelGGL(k_recombine_partial, dim3(nb), dim3(256), lds, s, rows, ld, N, first_candidate,
                        n_local, perm, weights, mu, block_partials);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_recombine_final, dim3((N + 255) / 256), dim3(256), 0, s, block_partials, nb,
-                       N, partial_local);
+    if (e != hipSuccess || !partial_local) return e;
+    hipLaunchKernelGGL(k_recombine_final, dim3((N + 31) / 32), dim3(256), 0, s, block_partials, nb, N,
+                       partial_local);
+    return hipGetLastError();
+}
+
+template <int EMAX, bool V_LDS>
+static hipError_t launch_update_t(hipStream_t s, const UpdateArgs &a, size_t lds, int threads)
+{
+    static size_t configured = 48 * 1024;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_update<EMAX, V_LDS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL((k_update<EMAX, V_LDS>), dim3(1), dim3(threads), lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_update(hipStream_t s, const UpdateArgs &a)
 {
-    if (a.m < 1 || a.m > LMCMA_HIP_MAX_VECTORS || a.N < 1 || a.n_partials < 1)
+    if (a.m < 1 || a.m > LMCMA_HIP_MAX_VECTORS || a.N < 1 || a.N > 512 || a.n_partials < 1)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_update, dim3(1), dim3(kUpdThreads), 0, s, a);
-    return hipGetLastError();
+    const size_t fixed = (2 * LMCMA_HIP_MAX_VECTORS + 2 * (size_t)a.N) * sizeof(double) +
+                         (2 * LMCMA_HIP_MAX_VECTORS + 4) * sizeof(int);
+    const size_t v_bytes = (size_t)a.m * a.N * sizeof(double);
+    const bool v_lds = v_bytes + fixed <= 150 * 1024;
+    const size_t lds = fixed + (v_lds ? v_bytes : 0);
+    int threads = 16 * a.m;
+    if (threads < 256) threads = 256;
+    threads = (threads + 63) & ~63;
+    const int emax = (a.N + 15) / 16;
+#define LMCMA_UPD(E)                                                             \
+    return v_lds ? launch_update_t<E, true>(s, a, lds, threads) : launch_update_t<E, false>(s, a, lds, threads)
+    if (emax <= 8) { LMCMA_UPD(8); }
+    if (emax <= 16) { LMCMA_UPD(16); }
+    LMCMA_UPD(32);
+#undef LMCMA_UPD
 }
 
 }  // namespace lmcma

@@ -1,0 +1,85 @@
+"""One population sharded over the GPUs of a node: one process per GPU,
+``torch.distributed`` (backend ``nccl`` = RCCL over xGMI) for the exchange steps.
+
+The reference is single-process (no collective anywhere in it); the partition is:
+rank g owns candidates [g*lambda/G, (g+1)*lambda/G).  The Philox counter is the
+global candidate index, so a candidate's row does not depend on G.  Per generation:
+
+  1. phase_local   sample + score the own candidates           (no communication)
+  2. all-gather    the own costs -> every rank holds all lambda costs
+  3. phase_rank    every rank ranks all costs (identical result) and sums the
+                   weighted rows of the elites it owns          -> one N-vector
+  4. all-gather    the per-rank elite partial sums (G x N doubles)
+  5. phase_update  every rank adds the G partial sums in rank order and runs the
+                   LM-CMA update; the replicated state stays bit-identical
+
+The elite exchange moves each rank's weighted elite sum rather than the elite
+rows themselves: mu = lambda/2 (reference lmcma.cpp:136), so "the rows of the
+elites" is on average half of every shard, while their weighted sum is N doubles.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import hip as hipmod
+
+
+class _DeviceArray:
+    """Exposes a raw device pointer through __cuda_array_interface__ so that torch
+    can alias a buffer the library owns (no copy)."""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def alias_tensor(ctx, which, dtype, device):
+    ptr, nbytes = ctx.buffer(which)
+    itemsize = torch.empty((), dtype=dtype).element_size()
+    typestr = {torch.float32: "<f4", torch.float64: "<f8", torch.int32: "<i4"}[dtype]
+    return torch.as_tensor(_DeviceArray(ptr, nbytes // itemsize, typestr), device=device)
+
+
+class HipShard:
+    """A HipContext plus torch views of the buffers the collectives move."""
+
+    def __init__(self, ctx, device):
+        self.ctx = ctx
+        self.cost_all = alias_tensor(ctx, hipmod.BUF_COST_ALL, torch.float32, device)
+        self.cost_local = alias_tensor(ctx, hipmod.BUF_COST_LOCAL, torch.float32, device)
+        self.partial_local = alias_tensor(ctx, hipmod.BUF_PARTIAL_LOCAL, torch.float64, device)
+        self.partial_all = alias_tensor(ctx, hipmod.BUF_PARTIAL_ALL, torch.float64, device)
+        self.N = ctx.N
+
+    def phase_local(self):
+        self.ctx.phase_local()
+
+    def phase_rank(self):
+        self.ctx.phase_rank()
+
+    def phase_update(self, n_partials):
+        self.ctx.phase_update(n_partials)
+
+
+def shard_range(lam_total, world, rank):
+    """Contiguous equal shards; lambda must divide evenly (all-gather needs equal blocks)."""
+    if lam_total % world:
+        raise ValueError("lambda_total must be a multiple of the number of ranks")
+    per = lam_total // world
+    return rank * per, per
+
+
+def sharded_generation(shard, group=None):
+    """One generation of a sharded population.  `shard` provides phase_local /
+    phase_rank / phase_update and the tensors cost_local, cost_all, partial_local,
+    partial_all (device tensors with nccl, CPU tensors with gloo)."""
+    world = dist.get_world_size(group)
+    shard.phase_local()
+    if world == 1:
+        shard.phase_rank()
+        shard.phase_update(0)
+        return
+    # cost_local is the rank's own block inside cost_all, so this is an in-place all-gather
+    dist.all_gather_into_tensor(shard.cost_all, shard.cost_local, group=group)
+    shard.phase_rank()
+    dist.all_gather_into_tensor(shard.partial_all[: world * shard.N], shard.partial_local, group=group)
+    shard.phase_update(world)

@@ -17,7 +17,7 @@ PAD_ENDPOINT, PAD_ZERO = 0, 1
 COST_TRAJECTORY, COST_EXTERNAL = 0, 1
 (BUF_ROWS_LOCAL, BUF_COST_LOCAL, BUF_COST_ALL, BUF_PARTIAL_LOCAL, BUF_PARTIAL_ALL, BUF_XMEAN,
  BUF_SORTED_COST, BUF_PERM) = range(8)
-KERNEL_CLASSES = ("sample", "cost", "select", "recombine", "update")
+KERNEL_CLASSES = ("sample", "cost", "select", "recombine", "update", "generate")
 
 
 def _dp(a):
@@ -164,6 +164,9 @@ class HipContext:
     def opt_init(self, xmean0, sigma0):
         xmean0 = _f64(xmean0)
         check_hip(self.lib.lmcma_hip_opt_init(self._h, _dp(xmean0), float(sigma0)), "lmcma_hip_opt_init")
+
+    def opt_reset(self):
+        check_hip(self.lib.lmcma_hip_opt_reset(self._h), "lmcma_hip_opt_reset")
 
     def run(self, generations):
         check_hip(self.lib.lmcma_hip_run(self._h, int(generations)), "lmcma_hip_run")

@@ -104,7 +104,8 @@ void orc_philox_normals(uint64_t seed, uint32_t generation, uint32_t candidate,
 {
     /* element quad q = n/4 uses counter (q, candidate, generation, 0); the two
      * word pairs feed two Box-Muller transforms: (r0,r1)->z[4q],z[4q+1] and
-     * (r2,r3)->z[4q+2],z[4q+3].  u = ((r>>8)+0.5)*2^-24 lies in (0,1).       */
+     * (r2,r3)->z[4q+2],z[4q+3].  u = ((r>>9)+0.5)*2^-23 lies in (0,1) and is
+     * exactly representable in fp32 as well (24 significant bits).          */
     const uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
     const double two_pi = 6.283185307179586476925286766559;
     for (int q = 0; 4 * q < N; ++q) {
@@ -112,8 +113,8 @@ void orc_philox_normals(uint64_t seed, uint32_t generation, uint32_t candidate,
         uint32_t r[4];
         orc_philox4x32_10(ctr, key, r);
         for (int h = 0; h < 2; ++h) {
-            double u1 = ((double)(r[2 * h] >> 8) + 0.5) * (1.0 / 16777216.0);
-            double u2 = ((double)(r[2 * h + 1] >> 8) + 0.5) * (1.0 / 16777216.0);
+            double u1 = ((double)(r[2 * h] >> 9) + 0.5) * (1.0 / 8388608.0);
+            double u2 = ((double)(r[2 * h + 1] >> 9) + 0.5) * (1.0 / 8388608.0);
             double rad = sqrt(-2.0 * log(u1));
             double a = two_pi * u2;
             int n = 4 * q + 2 * h;
@@ -511,9 +512,10 @@ void orc_lmcma_destroy(orc_lmcma *o)
     free(o);
 }
 
-static void lmcma_update(orc_lmcma *o)
+static void lmcma_update(orc_lmcma *o, const double *xmean_override)
 {
-    /* L/lmcma.cpp:313-424 */
+    /* L/lmcma.cpp:313-424.  xmean_override (test hook, normally NULL) replaces
+     * the recombination result, e.g. with a mean that was summed shard by shard. */
     const int N = o->N, lambda = o->lambda, mu = o->mu, nvectors = o->nvectors;
     int *t = o->t, *vec = o->vec;
     orc_sort(lambda, o->arfitness, o->arindex);
@@ -526,6 +528,8 @@ static void lmcma_update(orc_lmcma *o)
         for (int j = 0; j < N; ++j)
             o->xmean[j] += o->weights[i] * cur_x[j];
     }
+    if (xmean_override)
+        memcpy(o->xmean, xmean_override, (size_t)N * sizeof(double));
     for (int i = 0; i < N; ++i)
         o->pc[i] = (1 - o->cc) * o->pc[i] + sqrt(o->cc * (2 - o->cc) * o->mueff) *
                    (o->xmean[i] - o->xold[i]) / o->sigma;
@@ -632,7 +636,7 @@ void orc_lmcma_tell(orc_lmcma *o, const double *feedbacks, int num_feedbacks)
     if (feedback < o->best_f || o->counteval == 1)
         o->best_f = feedback;
     if (++o->sample_idx % o->lambda == 0) {
-        lmcma_update(o);
+        lmcma_update(o, NULL);
         if (o->z_source != ORC_Z_GIVEN)
             orc_lmcma_sample(o);
         o->sample_idx = 0;
@@ -645,7 +649,7 @@ void orc_lmcma_tell_all(orc_lmcma *o, const double *fitness)
         orc_lmcma_tell(o, &fitness[i], 1);
 }
 
-void orc_lmcma_update_only(orc_lmcma *o, const double *fitness)
+static void record_fitness(orc_lmcma *o, const double *fitness)
 {
     for (int i = 0; i < o->lambda; ++i) {
         double f = fitness[i];
@@ -654,7 +658,19 @@ void orc_lmcma_update_only(orc_lmcma *o, const double *fitness)
         if (f < o->best_f || o->counteval == 1)
             o->best_f = f;
     }
-    lmcma_update(o);
+}
+
+void orc_lmcma_update_only(orc_lmcma *o, const double *fitness)
+{
+    record_fitness(o, fitness);
+    lmcma_update(o, NULL);
+    o->sample_idx = 0;
+}
+
+void orc_lmcma_update_with_mean(orc_lmcma *o, const double *fitness, const double *xmean_new)
+{
+    record_fitness(o, fitness);
+    lmcma_update(o, xmean_new);
     o->sample_idx = 0;
 }
 

@@ -77,6 +77,8 @@ int orc_lmcma_done(const orc_lmcma *o);
 void orc_lmcma_tell_all(orc_lmcma *o, const double *fitness);
 /* only update(), then sample from caller-supplied Z[lambda][N] (z_source GIVEN) */
 void orc_lmcma_update_only(orc_lmcma *o, const double *fitness);
+/* the same, with the recombined mean supplied by the caller (a mean summed shard by shard) */
+void orc_lmcma_update_with_mean(orc_lmcma *o, const double *fitness, const double *xmean_new);
 void orc_lmcma_sample_given(orc_lmcma *o, const double *Z);
 void orc_lmcma_sample(orc_lmcma *o);
 /* overwrite the population (e.g. with rows another implementation drew) before update_only */

