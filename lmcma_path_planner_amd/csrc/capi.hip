@@ -242,14 +242,20 @@ int do_generate(lmcma_hip_ctx *c)
     return LMCMA_HIP_OK;
 }
 
-int do_select(lmcma_hip_ctx *c)
+// with_recombine: the ranking launch also leaves the elite partial sums of the local
+// rows in block_partials (*rows_out rows); only on the ranking-by-counting path
+int do_select(lmcma_hip_ctx *c, bool with_recombine, int *rows_out)
 {
     Timed tm(c, LMCMA_K_SELECT);
     // the two sorted-cost buffers alternate: this generation's list is written beside last one's
     c->parity ^= 1;
     c->sorted_cost = c->sorted_buf[c->parity];
+    RecombineArgs rc{c->rows, c->ld, c->N, c->first, c->nloc, c->weights, c->mu, c->block_partials};
+    const bool fuse = with_recombine && c->have_weights && select_can_recombine(c->lambda);
     HIP_TRY(launch_select(c->stream, c->cost_all, c->lambda, c->keys, c->sorted_cost, c->perm,
-                          c->opt_ready ? c->opt : nullptr, c->sorted_buf[c->parity ^ 1], c->psr_accum));
+                          c->opt_ready ? c->opt : nullptr, c->sorted_buf[c->parity ^ 1], c->psr_accum,
+                          fuse ? &rc : nullptr));
+    if (rows_out) *rows_out = fuse ? select_recombine_rows(c->first, c->nloc) : 0;
     c->selected = true;
     return LMCMA_HIP_OK;
 }
@@ -293,7 +299,9 @@ int one_generation(lmcma_hip_ctx *c)
         if ((rc = do_sample(c, nullptr)) != LMCMA_HIP_OK) return rc;
         if ((rc = do_evaluate(c)) != LMCMA_HIP_OK) return rc;
     }
-    if ((rc = do_select(c)) != LMCMA_HIP_OK) return rc;
+    int rows = 0;
+    if ((rc = do_select(c, true, &rows)) != LMCMA_HIP_OK) return rc;
+    if (rows > 0) return do_update(c, c->block_partials, rows);
     if ((rc = do_recombine(c, false)) != LMCMA_HIP_OK) return rc;
     return do_update(c, c->block_partials, recombine_num_blocks(c->mu));
 }
@@ -403,7 +411,8 @@ int lmcma_hip_create(const lmcma_hip_config *cfg, lmcma_hip_ctx **out)
     A(dalloc(&c->hi_f, ld));
     A(dalloc(&c->sc, 1));
     A(dalloc(&c->weights, (size_t)c->mu));
-    A(dalloc(&c->block_partials, (size_t)recombine_num_blocks(c->mu) * N));
+    A(dalloc(&c->block_partials,
+             (size_t)std::max(recombine_num_blocks(c->mu), select_recombine_rows(c->first, c->nloc)) * N));
     A(dalloc(&c->partial_local, N));
     A(dalloc(&c->partial_all, (size_t)kMaxPartials * N));
     A(dalloc(&c->xmean, N));
@@ -497,11 +506,15 @@ int lmcma_hip_set_grid(lmcma_hip_ctx *c, const void *cells, int nx, int ny, int 
     c->grid_bytes = bytes;
     c->c_start = host_grid_value(c, src, c->cfg.start);
     c->c_goal = host_grid_value(c, src, c->cfg.goal);
-    // Stage a bit grid in LDS when it fits beside the row tile (160 KiB per CU)
-    // and every block amortises the copy over enough candidates.
+    // A bit grid can be staged in LDS when it fits beside the row tile (160 KiB per
+    // CU).  Each block then copies the whole grid (16 bytes per lane and load) before
+    // its first lookup, so staging only pays once a block's own lookups outnumber those
+    // copy loads several times over; measured at lambda = 4096 on a 512^2 grid (16
+    // candidates per block), lookups straight from L2 are 4 us per generation faster.
     const size_t row_tile = (size_t)16 * c->ld * sizeof(float);
+    const size_t cand_per_block = ((size_t)c->nloc + 255) / 256;
     c->grid_lds = c->grid_type == LMCMA_GRID_BITS && bytes + row_tile <= 160 * 1024 &&
-                  (size_t)c->nloc * (size_t)(c->W + 2) >= 8 * (bytes / 16);
+                  cand_per_block * (size_t)(c->W + 2) >= 4 * (bytes / 16);
     if (const char *force = getenv("LMCMA_HIP_GRID_LDS")) {
         if (force[0] == '0') c->grid_lds = false;
         if (force[0] == '1' && c->grid_type == LMCMA_GRID_BITS && bytes + row_tile <= 160 * 1024)
@@ -624,7 +637,7 @@ int lmcma_hip_set_costs(lmcma_hip_ctx *c, int first, int count, const double *co
 int lmcma_hip_select(lmcma_hip_ctx *c, float *sorted_cost, int32_t *perm)
 {
     CTX_TRY(c);
-    int rc = do_select(c);
+    int rc = do_select(c, false, nullptr);
     if (rc != LMCMA_HIP_OK) return rc;
     if (sorted_cost)
         HIP_TRY(hipMemcpyAsync(sorted_cost, c->sorted_cost, c->lambda * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -855,8 +868,14 @@ int lmcma_hip_phase_rank(lmcma_hip_ctx *c)
 {
     CTX_TRY(c);
     if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
-    int rc = do_select(c);
+    int rows = 0;
+    int rc = do_select(c, true, &rows);
     if (rc != LMCMA_HIP_OK) return rc;
+    if (rows > 0) {
+        Timed tm(c, LMCMA_K_RECOMBINE);
+        HIP_TRY(launch_recombine_final(c->stream, c->block_partials, rows, c->N, c->partial_local));
+        return LMCMA_HIP_OK;
+    }
     return do_recombine(c, true);
 }
 

@@ -76,15 +76,31 @@ size_t select_workspace_bytes(int lambda);
 // keys_ws: select_workspace_bytes(lambda) bytes.  When opt != nullptr and opt->itr > 0 the
 // kernels also add, for every candidate, the number of entries of prev_sorted (last
 // generation's ascending costs) below its cost into *psr_accum (population success rule).
+// rc != nullptr (only when select_can_recombine(lambda)): the same launch also writes the
+// elite partial sums of the local rows, select_recombine_rows(...) rows of block_partials.
+struct RecombineArgs {
+    const float *rows;
+    int ld, N, first_candidate, n_local;
+    const double *weights;
+    int mu;
+    double *block_partials;
+};
+bool select_can_recombine(int lambda);
+int select_recombine_rows(int first_candidate, int n_local);
 hipError_t launch_select(hipStream_t s, const float *cost_all, int lambda, uint64_t *keys_ws,
                          float *sorted_cost, int32_t *perm, const OptScalars *opt,
-                         const float *prev_sorted, unsigned long long *psr_accum);
+                         const float *prev_sorted, unsigned long long *psr_accum,
+                         const RecombineArgs *rc);
 
 constexpr int kRecombineRanksPerBlock = 32;
 int recombine_num_blocks(int mu);
 hipError_t launch_recombine(hipStream_t s, const float *rows, int ld, int N, int first_candidate,
                             int n_local, const int32_t *perm, const double *weights, int mu,
                             double *block_partials, double *partial_local);
+
+// partial_local[N] = sum of the first `rows` rows of block_partials, in row order
+hipError_t launch_recombine_final(hipStream_t s, const double *block_partials, int rows, int N,
+                                  double *partial_local);
 
 struct UpdateArgs {
     OptScalars *opt;

@@ -83,31 +83,47 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
         }
         __syncthreads();  // staging done (first pass) / previous tile's rows consumed (later passes)
 
-        for (int t = 0; t < k; ++t) {
-            const float4 *v = reinterpret_cast<const float4 *>(Vp + (size_t)t * ld);
-            const float4 *b = reinterpret_cast<const float4 *>(Bp + (size_t)t * ld);
-            float d = 0.f;
+        // four direction vectors per pass: their dot products and lane reductions are
+        // independent, so the cross-lane latency of one hides behind the others; the
+        // rank-one updates are still applied in the order t = 0, 1, 2, ...
+        constexpr int U = 4;
+        for (int t0 = 0; t0 < k; t0 += U) {
+            float d[U];
 #pragma unroll
-            for (int j = 0; j < J; ++j) {
-                const int chunk = j * kLanes + lane;
-                if (chunk < nchunks) {
-                    const float4 vv = v[chunk];
-                    d = fmaf(vv.x, z[j].x, d);
-                    d = fmaf(vv.y, z[j].y, d);
-                    d = fmaf(vv.z, z[j].z, d);
-                    d = fmaf(vv.w, z[j].w, d);
+            for (int u = 0; u < U; ++u) {
+                d[u] = 0.f;
+                if (t0 + u < k) {
+                    const float4 *v = reinterpret_cast<const float4 *>(Vp + (size_t)(t0 + u) * ld);
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        const int chunk = j * kLanes + lane;
+                        if (chunk < nchunks) {
+                            const float4 vv = v[chunk];
+                            d[u] = fmaf(vv.x, z[j].x, d[u]);
+                            d[u] = fmaf(vv.y, z[j].y, d[u]);
+                            d[u] = fmaf(vv.z, z[j].z, d[u]);
+                            d[u] = fmaf(vv.w, z[j].w, d[u]);
+                        }
+                    }
                 }
             }
-            d = group_sum<kLanes>(d);
 #pragma unroll
-            for (int j = 0; j < J; ++j) {
-                const int chunk = j * kLanes + lane;
-                if (chunk < nchunks) {
-                    const float4 bb = b[chunk];
-                    acc[j].x = fmaf(d, bb.x, acc[j].x);
-                    acc[j].y = fmaf(d, bb.y, acc[j].y);
-                    acc[j].z = fmaf(d, bb.z, acc[j].z);
-                    acc[j].w = fmaf(d, bb.w, acc[j].w);
+            for (int u = 0; u < U; ++u) d[u] = group_sum<kLanes>(d[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (t0 + u < k) {
+                    const float4 *b = reinterpret_cast<const float4 *>(Bp + (size_t)(t0 + u) * ld);
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        const int chunk = j * kLanes + lane;
+                        if (chunk < nchunks) {
+                            const float4 bb = b[chunk];
+                            acc[j].x = fmaf(d[u], bb.x, acc[j].x);
+                            acc[j].y = fmaf(d[u], bb.y, acc[j].y);
+                            acc[j].z = fmaf(d[u], bb.z, acc[j].z);
+                            acc[j].w = fmaf(d[u], bb.w, acc[j].w);
+                        }
+                    }
                 }
             }
         }

@@ -216,37 +216,97 @@ __device__ __forceinline__ int count_below(const float *prev, int n, float c)
     return lo;
 }
 
-// PREV_LDS: last generation's sorted costs are staged in LDS for the binary searches
-template <bool PREV_LDS>
-__global__ __launch_bounds__(256) void k_rank_scatter(const float *__restrict__ cost, int lambda,
-                                                      const uint32_t *__restrict__ counts, int njt,
-                                                      float *__restrict__ sorted_cost,
-                                                      int32_t *__restrict__ perm,
-                                                      const OptScalars *__restrict__ opt,
-                                                      const float *__restrict__ prev_sorted,
-                                                      unsigned long long *__restrict__ psr_accum)
+// Second half of ranking by counting, 64 candidates per block:
+//   rank = sum of the per-tile counts; the candidate and its cost go to that position;
+//   the population-success-rule count against last generation's list (staged in LDS);
+//   and, when weights are given, the block's share of the elite recombination
+//   (lmcma.cpp:321-326): sum over its own candidates with rank < mu of
+//   weights[rank] * row, candidates in index order, as one row of block_partials.
+// The reference adds the elites in rank order; this adds the same terms grouped by
+// candidate index, which changes fp64 rounding only.
+constexpr int kFinishCands = 64;
+
+__global__ __launch_bounds__(256) void k_rank_finish(const float *__restrict__ cost, int lambda,
+                                                     const uint32_t *__restrict__ counts, int njt,
+                                                     float *__restrict__ sorted_cost,
+                                                     int32_t *__restrict__ perm,
+                                                     const OptScalars *__restrict__ opt,
+                                                     const float *__restrict__ prev_sorted,
+                                                     unsigned long long *__restrict__ psr_accum,
+                                                     const float *__restrict__ rows, int ld, int N,
+                                                     int first_candidate, int n_local,
+                                                     const double *__restrict__ weights, int mu,
+                                                     double *__restrict__ block_partials, int first_block)
 {
-    extern __shared__ __attribute__((aligned(16))) float s_prev[];
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+    // carve: recombination slots [nslots][ld] doubles | ranks [64] ints | previous list [lambda] floats
+    const int nq = ld >> 2;
+    const int nslots = weights ? 256 / nq : 0;
+    double *s_part = s_dyn;
+    int *s_rank = reinterpret_cast<int *>(s_dyn + (size_t)nslots * ld);
+    float *s_prev = reinterpret_cast<float *>(s_rank + kFinishCands);
     __shared__ unsigned long long s_wave[4];
+
     const bool psr = opt != nullptr && opt->itr > 0;  // uniform over the grid
-    if (PREV_LDS && psr) {
+    if (psr) {
         const float4 *src = reinterpret_cast<const float4 *>(prev_sorted);
         float4 *dst = reinterpret_cast<float4 *>(s_prev);
         for (int t = threadIdx.x; t < ((lambda + 3) >> 2); t += 256) dst[t] = src[t];
     }
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    float c = 0.f;
-    if (i < lambda) {
+    const int c0 = blockIdx.x * kFinishCands;
+    // four threads per candidate add the per-tile counts
+    {
+        const int t = threadIdx.x >> 2, part = threadIdx.x & 3;
+        const int i = c0 + t;
         uint32_t rank = 0;
-        for (int t = 0; t < njt; ++t) rank += counts[(size_t)t * lambda + i];
-        c = order_bits_inv(order_bits(cost[i]));  // NaN -> +inf, -0 -> +0 like the keys
-        sorted_cost[rank] = c;
-        perm[rank] = i;
+        if (i < lambda)
+            for (int jt = part; jt < njt; jt += 4) rank += counts[(size_t)jt * lambda + i];
+        rank += __shfl_xor(rank, 1, 64);
+        rank += __shfl_xor(rank, 2, 64);
+        if (part == 0) s_rank[t] = (i < lambda) ? (int)rank : 0x7fffffff;
     }
-    if (!psr) return;
     __syncthreads();
-    const unsigned long long below = (i < lambda) ? (unsigned long long)count_below(PREV_LDS ? s_prev : prev_sorted, lambda, c) : 0ull;
-    block_add_u64(below, psr_accum, s_wave);
+    unsigned long long below = 0ull;
+    if (threadIdx.x < kFinishCands) {
+        const int i = c0 + threadIdx.x;
+        if (i < lambda) {
+            const int rank = s_rank[threadIdx.x];
+            const float c = order_bits_inv(order_bits(cost[i]));  // NaN -> +inf, -0 -> +0 like the keys
+            sorted_cost[rank] = c;
+            perm[rank] = i;
+            if (psr) below = (unsigned long long)count_below(s_prev, lambda, c);
+        }
+    }
+    if (weights) {
+        const int slot = threadIdx.x / nq, q = threadIdx.x % nq;
+        if (slot < nslots) {
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            for (int t = slot; t < kFinishCands; t += nslots) {
+                const int rank = s_rank[t];
+                const int local = c0 + t - first_candidate;
+                if (rank < mu && local >= 0 && local < n_local) {
+                    const float4 x = reinterpret_cast<const float4 *>(rows + (size_t)local * ld)[q];
+                    const double w = weights[rank];
+                    a0 += w * (double)x.x; a1 += w * (double)x.y;
+                    a2 += w * (double)x.z; a3 += w * (double)x.w;
+                }
+            }
+            double *dst = s_part + (size_t)slot * ld + 4 * q;
+            dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
+        }
+    }
+    if (psr) block_add_u64(below, psr_accum, s_wave);  // contains a barrier
+    else __syncthreads();
+    if (weights) {
+        const int lb = (int)blockIdx.x - first_block;  // blocks without local candidates write nothing
+        const bool has_local = c0 + kFinishCands > first_candidate && c0 < first_candidate + n_local;
+        if (has_local)
+            for (int n = threadIdx.x; n < N; n += 256) {
+                double acc = 0.0;
+                for (int sl = 0; sl < nslots; ++sl) acc += s_part[(size_t)sl * ld + n];
+                block_partials[(size_t)lb * N + n] = acc;
+            }
+    }
 }
 
 // the same count for the sorting paths: one thread per candidate, list in global memory
@@ -276,9 +336,20 @@ size_t select_workspace_bytes(int lambda)
 
 int select_num_tiles(int lambda) { return (lambda + kSortTile - 1) / kSortTile; }
 
+bool select_can_recombine(int lambda)
+{
+    return lambda <= kRankCountMax && getenv("LMCMA_HIP_SELECT_SORT") == nullptr;
+}
+
+int select_recombine_rows(int first_candidate, int n_local)
+{
+    return (first_candidate + n_local + kFinishCands - 1) / kFinishCands - first_candidate / kFinishCands;
+}
+
 hipError_t launch_select(hipStream_t s, const float *cost_all, int lambda, uint64_t *keys_ws,
                          float *sorted_cost, int32_t *perm, const OptScalars *opt,
-                         const float *prev_sorted, unsigned long long *psr_accum)
+                         const float *prev_sorted, unsigned long long *psr_accum,
+                         const RecombineArgs *rc)
 {
     if (lambda <= 0) return hipErrorInvalidValue;
     if (!prev_sorted || !psr_accum) opt = nullptr;
@@ -295,12 +366,25 @@ hipError_t launch_select(hipStream_t s, const float *cost_all, int lambda, uint6
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        // lambda <= 16384: the previous list (<= 64 KiB) fits the default dynamic LDS limit
-        const size_t lds = opt ? (size_t)((lambda + 3) & ~3) * sizeof(float) : 0;
-        hipLaunchKernelGGL(k_rank_scatter<true>, dim3(it), dim3(256), lds, s, cost_all, lambda, counts, njt,
-                           sorted_cost, perm, opt, prev_sorted, psr_accum);
+        const int nblocks = (lambda + kFinishCands - 1) / kFinishCands;
+        const int nslots = rc ? 256 / (rc->ld >> 2) : 0;
+        const size_t lds = (rc ? (size_t)nslots * rc->ld * sizeof(double) : 0) + kFinishCands * sizeof(int) +
+                           (opt ? (size_t)((lambda + 3) & ~3) * sizeof(float) : 0);
+        static size_t configured = 48 * 1024;
+        if (lds > configured) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rank_finish),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            configured = lds;
+        }
+        hipLaunchKernelGGL(k_rank_finish, dim3(nblocks), dim3(256), lds, s, cost_all, lambda, counts, njt,
+                           sorted_cost, perm, opt, prev_sorted, psr_accum, rc ? rc->rows : nullptr,
+                           rc ? rc->ld : 4, rc ? rc->N : 0, rc ? rc->first_candidate : 0, rc ? rc->n_local : 0,
+                           rc ? rc->weights : nullptr, rc ? rc->mu : 0, rc ? rc->block_partials : nullptr,
+                           rc ? rc->first_candidate / kFinishCands : 0);
         return hipGetLastError();
     }
+    if (rc) return hipErrorInvalidValue;  // the fused recombination exists only on the counting path
     const int ntiles = select_num_tiles(lambda);
     hipLaunchKernelGGL(k_sort_tiles, dim3(ntiles), dim3(kThreads), 0, s, cost_all, lambda, keys_ws,
                        sorted_cost, perm, ntiles == 1 ? 1 : 0);

@@ -334,6 +334,15 @@ hipError_t launch_recombine(hipStream_t s, const float *rows, int ld, int N, int
     return hipGetLastError();
 }
 
+hipError_t launch_recombine_final(hipStream_t s, const double *block_partials, int rows, int N,
+                                  double *partial_local)
+{
+    if (rows < 1 || N < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_recombine_final, dim3((N + 31) / 32), dim3(256), 0, s, block_partials, rows, N,
+                       partial_local);
+    return hipGetLastError();
+}
+
 template <int EMAX, bool V_LDS>
 static hipError_t launch_update_t(hipStream_t s, const UpdateArgs &a, size_t lds, int threads)
 {
