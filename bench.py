@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", type=int, default=2, help="benchmark configuration (2 = the headline one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (RCCL) for real runs; gloo only to rehearse the "
+                    "N > 1 code path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
     import torch
@@ -97,15 +99,24 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     prob = grids.benchmark_problem(args.config)
     lam_local = prob.lam if args.config <= 3 else prob.lam // 8   # cfg4/5 are quoted as 8-GPU populations
     lam_total = lam_local * world
-    stream = torch.cuda.current_stream().cuda_stream if world > 1 else None
+    stream = None
+    if world > 1:
+        # kernels and collectives are ordered on one non-default torch stream
+        tstream = torch.cuda.Stream(device)
+        torch.cuda.set_stream(tstream)
+        stream = tstream.cuda_stream
     ctx = hip.HipContext(prob.N, lam_total, prob.m, dims=prob.dims, waypoints=prob.W, lambda_local=lam_local,
                          first_candidate=rank * lam_local, seed=42, start=prob.start, goal=prob.goal,
                          w_len=prob.weights[0], w_grid=prob.weights[1], w_smooth=prob.weights[2],

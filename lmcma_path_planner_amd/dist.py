@@ -68,10 +68,25 @@ def shard_range(lam_total, world, rank):
     return rank * per, per
 
 
+def _all_gather(out, inp, group):
+    """all_gather_into_tensor; device tensors go straight to RCCL, and through a host
+    copy on any other backend (gloo is only used to rehearse the loop without RCCL)."""
+    if inp.is_cuda and dist.get_backend(group) != "nccl":
+        host_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host_out, inp.cpu(), group=group)
+        out.copy_(host_out)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
 def sharded_generation(shard, group=None):
     """One generation of a sharded population.  `shard` provides phase_local /
     phase_rank / phase_update and the tensors cost_local, cost_all, partial_local,
-    partial_all (device tensors with nccl, CPU tensors with gloo)."""
+    partial_all (device tensors with nccl, CPU tensors with gloo).
+
+    The library's kernels and the collectives must be ordered on one stream: create
+    the HipContext on torch's current stream (``stream=torch.cuda.current_stream().cuda_stream``
+    of a non-default stream) and call this function with that stream current."""
     world = dist.get_world_size(group)
     shard.phase_local()
     if world == 1:
@@ -79,7 +94,7 @@ def sharded_generation(shard, group=None):
         shard.phase_update(0)
         return
     # cost_local is the rank's own block inside cost_all, so this is an in-place all-gather
-    dist.all_gather_into_tensor(shard.cost_all, shard.cost_local, group=group)
+    _all_gather(shard.cost_all, shard.cost_local, group)
     shard.phase_rank()
-    dist.all_gather_into_tensor(shard.partial_all[: world * shard.N], shard.partial_local, group=group)
+    _all_gather(shard.partial_all[: world * shard.N], shard.partial_local, group)
     shard.phase_update(world)

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 outputs (under gpurun_out/) into the small summaries kept here.
+
+    python profiles/collect.py <tag> <kernel-trace dir> [<pmc FETCH_SIZE dir> <pmc WRITE_SIZE dir>]
+
+Writes profiles/<tag>_kernel_stats.csv (the --kernel-trace --stats summary as is),
+profiles/<tag>_hbm_traffic.csv (per kernel: launches, mean FETCH_SIZE and WRITE_SIZE
+in KB per launch, as the counters report them) and profiles/traffic_cfg2.json (bytes
+per launch per kernel class, FETCH_SIZE + WRITE_SIZE, read by bench.py).
+FETCH_SIZE on gfx950 reports half the bytes of wide (16 B/lane) coalesced streaming
+reads; the figures here are the raw counter values, not corrected."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CLASS_OF = {"k_generate": "generate", "k_sample": "sample", "k_cost": "cost", "k_rank_count": "select",
+            "k_rank_finish": "select", "k_sort_tiles": "select", "k_merge_rank": "select", "k_psr_count": "select",
+            "k_recombine_partial": "recombine", "k_recombine_final": "recombine", "k_update": "update"}
+
+
+def short(name):
+    return name.replace("lmcma::(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
+
+
+def pmc(directory):
+    f = glob.glob(os.path.join(directory, "**", "*_counter_collection.csv"), recursive=True)[0]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        agg[k][0] += 1
+        agg[k][1] += float(r["Counter_Value"])
+    return agg
+
+
+def main():
+    tag, trace = sys.argv[1], sys.argv[2]
+    stats = glob.glob(os.path.join(trace, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    shutil.copy(stats, os.path.join(HERE, tag + "_kernel_stats.csv"))
+    if len(sys.argv) >= 5:
+        fe, wr = pmc(sys.argv[3]), pmc(sys.argv[4])
+        per_class = collections.defaultdict(float)
+        with open(os.path.join(HERE, tag + "_hbm_traffic.csv"), "w") as out:
+            out.write("kernel,launches,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch\n")
+            for k in sorted(fe):
+                f_kb = fe[k][1] / fe[k][0]
+                w_kb = wr[k][1] / wr[k][0] if k in wr else 0.0
+                out.write("%s,%d,%.3f,%.3f\n" % (k, fe[k][0], f_kb, w_kb))
+                if k in CLASS_OF:
+                    per_class[CLASS_OF[k]] += (f_kb + w_kb) * 1024.0
+        json.dump({k: round(v) for k, v in per_class.items()}, open(os.path.join(HERE, "traffic_cfg2.json"), "w"),
+                  indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

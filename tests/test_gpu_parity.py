@@ -436,3 +436,59 @@ def test_error_reporting(hip):
     with pytest.raises(LmcmaError, match="nz must be 1"):
         ctx.set_grid(np.zeros((2, 4, 4), dtype=np.uint8))
     ctx.close()
+
+
+def test_two_shards_on_one_gpu_match_the_unsharded_population(hip):
+    """The sharded phases with the exchange steps done by hand (device-to-device copies
+    through torch views of the library's buffers, as the RCCL path aliases them)."""
+    import torch
+    from lmcma_path_planner_amd import dist as shard_mod
+    from lmcma_path_planner_amd import grids
+    prob = grids.benchmark_problem(2)
+    lam, half, gens = 1024, 512, 12
+    dev = torch.device("cuda", 0)
+
+    def make(first, nloc):
+        ctx = hip.HipContext(prob.N, lam, prob.m, dims=2, waypoints=prob.W, lambda_local=nloc, first_candidate=first,
+                             start=prob.start, goal=prob.goal, seed=99)
+        ctx.set_grid(prob.occ)
+        ctx.set_bounds(prob.lo, prob.hi)
+        ctx.opt_init(prob.x0, prob.sigma0)
+        return ctx
+
+    whole = make(0, lam)
+    parts = [make(0, half), make(half, half)]
+    shards = [shard_mod.HipShard(c, dev) for c in parts]
+    N = prob.N
+    for _ in range(gens):
+        whole.phase_local()
+        whole.phase_rank()
+        whole.phase_update(0)
+        for c in parts:
+            c.phase_local()
+        for c in parts:
+            c.synchronize()
+        # "all-gather" of the costs: each shard's block into the other's full vector
+        shards[0].cost_all[half:].copy_(shards[1].cost_local)
+        shards[1].cost_all[:half].copy_(shards[0].cost_local)
+        torch.cuda.synchronize()
+        for c in parts:
+            c.phase_rank()
+        for c in parts:
+            c.synchronize()
+        for s in shards:
+            s.partial_all[:N].copy_(shards[0].partial_local)
+            s.partial_all[N:2 * N].copy_(shards[1].partial_local)
+        torch.cuda.synchronize()
+        for c in parts:
+            c.phase_update(2)
+    w = whole.opt_get()
+    a, b = parts[0].opt_get(), parts[1].opt_get()
+    np.testing.assert_array_equal(a["xmean"], b["xmean"])              # replicas stay bit-identical
+    assert a["sigma"] == b["sigma"] and a["best_f"] == b["best_f"] == w["best_f"]
+    np.testing.assert_allclose(a["xmean"], w["xmean"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(a["sigma"], w["sigma"], rtol=1e-11)
+    # the last generation's costs: the two halves are the unsharded run's costs
+    np.testing.assert_allclose(np.concatenate([parts[0].costs(), parts[1].costs()]), whole.costs(), rtol=1e-5)
+    for c in parts + [whole]:
+        c.close()
