@@ -47,7 +47,8 @@ enum { LMCMA_COST_TRAJECTORY = 0, LMCMA_COST_EXTERNAL = 1 };
 
 /* limits of the kernels (checked by lmcma_hip_create) */
 #define LMCMA_HIP_MAX_PARAMS 512
-#define LMCMA_HIP_MAX_VECTORS 64
+#define LMCMA_HIP_MAX_VECTORS 64            /* device-resident update (lmcma_hip_opt_init)   */
+#define LMCMA_HIP_MAX_VECTORS_STEPWISE 4096 /* stepwise API: the caller keeps the state      */
 #define LMCMA_HIP_MAX_LAMBDA (1 << 20)
 
 typedef struct lmcma_hip_ctx lmcma_hip_ctx;

@@ -362,8 +362,8 @@ int lmcma_hip_create(const lmcma_hip_config *cfg, lmcma_hip_ctx **out)
     if (cfg->lambda_local < 1 || cfg->first_candidate < 0 ||
         cfg->first_candidate + cfg->lambda_local > cfg->lambda_total)
         return fail(LMCMA_HIP_ERR_ARG, "local candidate range lies outside the population");
-    if (cfg->m < 1 || cfg->m > LMCMA_HIP_MAX_VECTORS)
-        return fail(LMCMA_HIP_ERR_UNSUPPORTED, "m must be in [1, 64]");
+    if (cfg->m < 1 || cfg->m > LMCMA_HIP_MAX_VECTORS_STEPWISE)
+        return fail(LMCMA_HIP_ERR_UNSUPPORTED, "m must be in [1, 4096]");
     if (cfg->mu < 1 || cfg->mu > cfg->lambda_total) return fail(LMCMA_HIP_ERR_ARG, "mu must be in [1, lambda]");
     if (cfg->z_source != LMCMA_Z_HOST && cfg->z_source != LMCMA_Z_PHILOX)
         return fail(LMCMA_HIP_ERR_ARG, "unknown z_source");
@@ -738,6 +738,8 @@ int lmcma_hip_opt_init(lmcma_hip_ctx *c, const double *xmean0, double sigma0)
 {
     CTX_TRY(c);
     if (!xmean0 || !(sigma0 > 0.0)) return fail(LMCMA_HIP_ERR_ARG, "xmean0 and a positive sigma0 are needed");
+    if (c->m > LMCMA_HIP_MAX_VECTORS)
+        return fail(LMCMA_HIP_ERR_UNSUPPORTED, "the device-resident update keeps at most 64 direction vectors");
     HIP_TRY(hipStreamSynchronize(c->stream));
     const int N = c->N, mu = c->mu, m = c->m;
     // weights and mueff, lmcma.cpp:144-156

@@ -492,3 +492,41 @@ def test_two_shards_on_one_gpu_match_the_unsharded_population(hip):
     np.testing.assert_allclose(np.concatenate([parts[0].costs(), parts[1].costs()]), whole.costs(), rtol=1e-5)
     for c in parts + [whole]:
         c.close()
+
+
+def test_cpp_examples_against_the_drop_in_header():
+    """examples/*.cpp are written against include/lmcma.hpp like a caller of the reference's
+    header; the binaries are built on the CPU box by __graft_entry__.build()."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    toy = os.path.join(root, "examples", "bin", "toy_ask_tell")
+    plan = os.path.join(root, "examples", "bin", "plan_path")
+    assert os.path.exists(toy) and os.path.exists(plan), "run __graft_entry__.build() first"
+    out = subprocess.run([toy, "3", "1000"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    best = float(re.search(r"best (-?[0-9.]+)", out.stdout).group(1))
+    assert min(abs(best + 4.0007), abs(best + 2.0013)) < 2e-3
+    out = subprocess.run([plan, "100", "32", "64", "8", "400"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "generations 400 evaluations 25600" in out.stdout
+    assert float(re.search(r"best cost ([0-9.]+)", out.stdout).group(1)) < 2000.0   # straight line: 25596
+
+
+def test_stepwise_api_with_the_reference_choice_m_equal_lambda(hip, oracle):
+    """m = lambda = 256 direction vectors (the reference's only setting) through the stepwise API."""
+    N, lam = 64, 256
+    o = _evolved_oracle(oracle, N, lam, lam, 40)
+    st = _state_of(o)
+    assert st["k"] == 40
+    Z = np.random.default_rng(3).normal(size=(lam, N))
+    o.sample_given(Z.astype(np.float32).astype(np.float64))
+    ctx = hip.HipContext(N, lam, lam, z_source=hip.Z_HOST, cost_source=hip.COST_EXTERNAL)
+    ctx.set_state(st["xmean"], st["sigma"], st["V"], st["PC"], st["nj"], st["M"])
+    ctx.sample(40, Z)
+    scale = np.abs(st["xmean"]).max() + np.abs(o.arx - st["xmean"]).max() + 1.0
+    assert np.max(np.abs(ctx.rows() - o.arx)) <= 3e-6 * scale
+    from lmcma_path_planner_amd._lib import LmcmaError
+    with pytest.raises(LmcmaError, match="at most 64"):
+        ctx.opt_init(np.zeros(N), 1.0)
+    ctx.close()
