@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblmcma_hip.so")
+LIB_PATH = os.environ.get("LMCMA_HIP_LIB", os.path.join(_HERE, "lib", "liblmcma_hip.so"))
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_float_p = ctypes.POINTER(ctypes.c_float)

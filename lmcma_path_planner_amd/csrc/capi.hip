@@ -955,6 +955,17 @@ int lmcma_hip_synchronize(lmcma_hip_ctx *c)
     return LMCMA_HIP_OK;
 }
 
+#ifdef LMCMA_DIAG
+hipError_t lmcma_diag_update_stamps(unsigned long long *out16);
+int lmcma_hip_diag_update_stamps(lmcma_hip_ctx *c, unsigned long long *out16)
+{
+    CTX_TRY(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(lmcma_diag_update_stamps(out16));
+    return LMCMA_HIP_OK;
+}
+#endif
+
 int lmcma_hip_timing_enable(lmcma_hip_ctx *c, int on)
 {
     CTX_TRY(c);

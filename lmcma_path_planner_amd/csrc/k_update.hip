@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_recombine_partial(const float *__restri
 // sum of `count` rows of src[count][N] in row order, 8 threads per coordinate:
 // thread j of a coordinate adds rows j, j+8, ...; the 8 partial sums are then
 // added in lane order 0..7 (fixed tree).
-__device__ __forceinline__ double strided_sum8(const double *__restrict__ src, int count, int N, int n, int j)
+__device__ __forceinline__ double strided_partial8(const double *__restrict__ src, int count, int N, int n, int j)
 {
     double acc = 0.0;
     for (int b0 = j; b0 < count; b0 += 64) {
@@ -68,11 +68,21 @@ __device__ __forceinline__ double strided_sum8(const double *__restrict__ src, i
         for (int u = 0; u < 8; ++u)
             if (b0 + 8 * u < count) acc += r[u];
     }
-    // lanes j = 0..7 are consecutive lanes of one wave
+    return acc;
+}
+
+// the 8 partial sums of lanes j = 0..7 (consecutive lanes of one wave) added in lane order
+__device__ __forceinline__ double lanes8_sum(double acc)
+{
     double total = 0.0;
 #pragma unroll
     for (int s = 0; s < 8; ++s) total += __shfl(acc, (threadIdx.x & 56) + s, 64);
     return total;
+}
+
+__device__ __forceinline__ double strided_sum8(const double *__restrict__ src, int count, int N, int n, int j)
+{
+    return lanes8_sum(strided_partial8(src, count, N, n, j));
 }
 
 __global__ __launch_bounds__(256) void k_recombine_final(const double *__restrict__ block_partials,
@@ -87,7 +97,44 @@ __global__ __launch_bounds__(256) void k_recombine_final(const double *__restric
 }
 
 // ---- update ---------------------------------------------------------------------
-//
+
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+
+__device__ __forceinline__ double fast_rsq(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-x * y, y, 1.0);
+    return fma(0.5 * y, e, y);
+}
+
+// L/:388-389: lj = (1/(sq nv)) (1 - 1/sqrt(1 + ratio nv)), with the reciprocal and the
+// reciprocal square root from the hardware estimate plus two Newton steps (full fp64
+// precision at a fraction of the latency of the IEEE divide and sqrt sequences)
+__device__ __forceinline__ double lj_of(double nv, double sq, double ratio)
+{
+    return fast_rcp(sq * nv) * (1 - fast_rsq(1 + ratio * nv));
+}
+
+#ifdef LMCMA_DIAG
+// diagnostic build only: wall-clock stamps (100 MHz counter) of the phases of k_update
+__device__ unsigned long long g_update_stamps[16];
+#define STAMP(i)                                                            \
+    do {                                                                    \
+        if (threadIdx.x == 0) g_update_stamps[i] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
 // One workgroup; 16 lanes own one direction vector, EMAX coordinates per lane held
 // in registers.  V_LDS: finished vectors are published through LDS (m * N * 8
 // bytes), otherwise through their home rows in global memory.  Global stores are
@@ -110,11 +157,17 @@ __global__ __launch_bounds__(1024) void k_update(const UpdateArgs a)
     double *s_xm = s_pc + N;                                    // [N] new mean
     double *s_lj = s_xm + N;                                    // [64], slot-indexed
     double *s_nj = s_lj + LMCMA_HIP_MAX_VECTORS;                // [64], slot-indexed
-    int *s_t = reinterpret_cast<int *>(s_nj + LMCMA_HIP_MAX_VECTORS);  // [64]
+    double *s_nv = s_nj + LMCMA_HIP_MAX_VECTORS;                // [64], |v_i|^2 by position i
+    double *s_ljp = s_nv + LMCMA_HIP_MAX_VECTORS;               // [64], lj of the untouched vectors by position
+    int *s_t = reinterpret_cast<int *>(s_ljp + LMCMA_HIP_MAX_VECTORS);  // [64]
     int *s_vec = s_t + LMCMA_HIP_MAX_VECTORS;                   // [64]
     int *s_misc = s_vec + LMCMA_HIP_MAX_VECTORS;                // imin, isz, newidx
     int &s_imin = s_misc[0], &s_isz = s_misc[1], &s_newidx = s_misc[2];
 
+    STAMP(0);
+#ifdef LMCMA_DIAG
+    if (threadIdx.x == 0) g_update_stamps[10] = __builtin_amdgcn_s_memtime();
+#endif
     if (tid < m) {
         s_t[tid] = a.t[tid];
         s_vec[tid] = a.vec[tid];
@@ -128,25 +181,11 @@ __global__ __launch_bounds__(1024) void k_update(const UpdateArgs a)
         psr_in = *a.psr_accum;
         best_in = a.sorted_cost[0];
     }
-
-    // L/:316-329: new mean from the rank-ordered partial sums, evolution path.
-    // 8 threads per coordinate add the partials (see strided_sum8); thread 0 of each
-    // coordinate keeps the results in registers when one pass covers all coordinates.
-    const double pc_gain = sqrt(cc * (2 - cc) * o.mueff);
-    for (int n0 = 0; n0 < N; n0 += T / 8) {
-        const int n = n0 + (tid >> 3);
-        const int nn = n < N ? n : N - 1;
-        const double xnew = strided_sum8(a.partials, a.n_partials, N, nn, tid & 7);
-        if (n < N && (tid & 7) == 0) {
-            const double xold = a.xmean[n];
-            const double pcn = (1 - cc) * a.pc[n] + pc_gain * (xnew - xold) / sigma;
-            s_pc[n] = pcn;
-            s_xm[n] = xnew;
-        }
-    }
     __syncthreads();
+    STAMP(1);
 
-    // L/:331-364: which slot receives the new direction
+    // L/:331-364: which slot receives the new direction (needs only the slot tables,
+    // so it runs first and the vector loads below overlap the partial-sum loads)
     if (tid == 0) {
         int imin = 1;
         if (itr < m) {
@@ -179,7 +218,61 @@ __global__ __launch_bounds__(1024) void k_update(const UpdateArgs a)
         s_newidx = newidx;
     }
     __syncthreads();
+    STAMP(2);
     const int imin = s_imin, isz = s_isz, newidx = s_newidx;
+
+    // One 16-lane group per stored direction; the loads of its vector and of its
+    // evolution path are issued here, ahead of the partial-sum reduction.
+    const bool own = grp < isz;
+    const int slot = own ? s_t[grp] : 0;
+    const bool rebuild = own && grp >= imin;
+    const bool newest = own && slot == newidx;  // L/:365-366: takes the new evolution path
+    double av[EMAX], pcq[EMAX];  // the vector and its evolution path pc_arr[slot]
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        const int n = e * 16 + lane;
+        const bool in = own && n < N;
+        pcq[e] = (in && !newest) ? a.pc_arr[(size_t)slot * N + n] : 0.0;
+        av[e] = (in && !rebuild) ? a.v_arr[(size_t)slot * N + n] : 0.0;
+    }
+
+    // L/:316-329: new mean from the rank-ordered partial sums, evolution path.
+    // 8 threads per coordinate add the partials with the summation tree of strided_sum8;
+    // the loads of all passes are issued before the first cross-lane step.
+    const double pc_gain = sqrt(cc * (2 - cc) * o.mueff);
+    {
+        constexpr int kPasses = 4;  // 1024 threads / 8 = 128 coordinates per pass, N <= 512
+        double acc[kPasses];
+        const int j = tid & 7;
+#pragma unroll
+        for (int ps = 0; ps < kPasses; ++ps) {
+            const int n = ps * (T / 8) + (tid >> 3);
+            acc[ps] = (ps * (T / 8) < N) ? strided_partial8(a.partials, a.n_partials, N, n < N ? n : N - 1, j) : 0.0;
+        }
+#ifdef LMCMA_DIAG
+        if (acc[0] == 1.2345e300) g_update_stamps[15] = 1;  // forces the loads to complete here
+        STAMP(8);
+#endif
+#pragma unroll
+        for (int ps = 0; ps < kPasses; ++ps) {
+            if (ps * (T / 8) < N) {  // uniform
+                const int n = ps * (T / 8) + (tid >> 3);
+                const double xnew = lanes8_sum(acc[ps]);
+#ifdef LMCMA_DIAG
+                if (xnew == 1.2345e300) g_update_stamps[15] = 2;
+                if (ps == 0) STAMP(9);
+#endif
+                if (n < N && j == 0) {
+                    const double xold = a.xmean[n];
+                    const double pcn = (1 - cc) * a.pc[n] + pc_gain * (xnew - xold) / sigma;
+                    s_pc[n] = pcn;
+                    s_xm[n] = xnew;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    STAMP(3);
 
     // L/:375-390 with invAz (:449-463).  Vector i is v_i = T_{i-1} ... T_0 pc_i with
     // T_j = K I - lj_j v_j v_j^T.  The reference finishes vector i before it starts
@@ -187,58 +280,76 @@ __global__ __launch_bounds__(1024) void k_update(const UpdateArgs a)
     // time (one 16-lane group per vector, the vector in registers), so each vector
     // still sees exactly the reference's sequence of operations.  Vectors before imin
     // keep last generation's value (L/:375 starts at imin).
-    const bool own = grp < isz;
-    const int slot = own ? s_t[grp] : 0;
-    const bool rebuild = own && grp >= imin;
-    double av[EMAX], pcq[EMAX];  // the vector and its evolution path pc_arr[slot]
+    //
+    // The squared norm of every vector is carried along instead of being summed again
+    // after the last transform: |K a - d v|^2 = K^2 |a|^2 - 2 K d (v.a) + d^2 |v|^2, all of
+    // whose terms are already in registers; so a step needs one cross-lane sum only.
+    double aa = 0.0;
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
         const int n = e * 16 + lane;
-        const bool in = own && n < N;
-        // L/:365-366: the new evolution path enters the store at slot newidx
-        pcq[e] = in ? (slot == newidx ? s_pc[n] : a.pc_arr[(size_t)slot * N + n]) : 0.0;
-        av[e] = rebuild ? pcq[e] : (in ? a.v_arr[(size_t)slot * N + n] : 0.0);
-        if (V_LDS && in && !rebuild) s_v[(size_t)grp * N + n] = av[e];
+        if (newest && n < N) pcq[e] = s_pc[n];
+        if (rebuild) av[e] = pcq[e];
+        aa += av[e] * av[e];
+        if (V_LDS && own && !rebuild && n < N) s_v[(size_t)grp * N + n] = av[e];
     }
-    const double sq = sqrt(1 - c1), ratio = c1 / (1 - c1), K = o.K;
-    for (int i = 0; i < isz; ++i) {
-        // vector i has received T_0..T_{i-1}: it is final, its owner publishes it
-        if (grp == i && rebuild) {
-            double nv = 0.0;
-#pragma unroll
-            for (int e = 0; e < EMAX; ++e) nv += av[e] * av[e];
-            nv = row16_sum(nv);
-            double *dst = V_LDS ? s_v + (size_t)i * N : a.v_arr + (size_t)slot * N;
-#pragma unroll
-            for (int e = 0; e < EMAX; ++e) {
-                const int n = e * 16 + lane;
-                if (n < N) dst[n] = av[e];
-            }
-            if (lane == 0) {
-                s_nj[slot] = (sq / nv) * (sqrt(1 + ratio * nv) - 1);
-                s_lj[slot] = (1 / (sq * nv)) * (1 - (1 / sqrt(1 + ratio * nv)));
-            }
-        }
-        __syncthreads();
-        // T_i on every later vector that is being rebuilt.  The next publication writes
-        // row i+1 and other coefficient words, so one barrier per step is enough.
-        if (rebuild && grp > i) {
-            const int slot_i = s_t[i];
-            const double *vi = V_LDS ? s_v + (size_t)i * N : a.v_arr + (size_t)slot_i * N;
-            double vv[EMAX];
-            double d = 0.0;
-#pragma unroll
-            for (int e = 0; e < EMAX; ++e) {
-                const int n = e * 16 + lane;
-                vv[e] = n < N ? vi[n] : 0.0;
-                d += vv[e] * av[e];
-            }
-            d = s_lj[slot_i] * row16_sum(d);
-#pragma unroll
-            for (int e = 0; e < EMAX; ++e) av[e] = K * av[e] - d * vv[e];
-        }
+    aa = row16_sum(aa);
+    if (own && !rebuild && lane == 0) {
+        s_nv[grp] = aa;
+        s_ljp[grp] = s_lj[slot];
     }
     __syncthreads();
+    STAMP(4);
+    const double sq = sqrt(1 - c1), ratio = c1 / (1 - c1), K = o.K;
+    for (int i = 0; i < isz; ++i) {
+        const bool fresh = i >= imin;  // same for every thread
+        if (fresh) {
+            // vector i has received T_0..T_{i-1}: it is final, its owner publishes it and its
+            // squared norm; vectors before imin were published above, once
+            if (grp == i) {
+                double *dst = V_LDS ? s_v + (size_t)i * N : a.v_arr + (size_t)slot * N;
+#pragma unroll
+                for (int e = 0; e < EMAX; ++e) {
+                    const int n = e * 16 + lane;
+                    if (n < N) dst[n] = av[e];
+                }
+                if (lane == 0) s_nv[i] = aa;
+            }
+            // The next publication writes row i+1 and another norm word, so one barrier per
+            // step is enough.
+            __syncthreads();
+        }
+        // T_i on every later vector that is being rebuilt
+        if (rebuild && grp > i) {
+            const double *vi = V_LDS ? s_v + (size_t)i * N : a.v_arr + (size_t)s_t[i] * N;
+            double vv[EMAX];
+            double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+            for (int e = 0; e < EMAX; e += 2) {
+                const int n0 = e * 16 + lane, n1 = (e + 1) * 16 + lane;
+                vv[e] = n0 < N ? vi[n0] : 0.0;
+                vv[e + 1] = n1 < N ? vi[n1] : 0.0;
+                p0 += vv[e] * av[e];
+                p1 += vv[e + 1] * av[e + 1];
+            }
+            const double nvi = s_nv[i];
+            // every group derives lj_i from the published norm itself (arithmetic that hides
+            // behind the LDS reads above) instead of waiting for the owner to do it
+            const double lji = fresh ? lj_of(nvi, sq, ratio) : s_ljp[i];
+            const double p = row16_sum(p0 + p1);
+            const double d = lji * p;
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) av[e] = K * av[e] - d * vv[e];
+            aa = K * K * aa - 2.0 * K * d * p + d * d * nvi;
+        }
+    }
+    // L/:386-389 for the rebuilt vectors
+    if (rebuild && lane == 0) {
+        s_nj[slot] = (sq / aa) * (sqrt(1 + ratio * aa) - 1);
+        s_lj[slot] = lj_of(aa, sq, ratio);
+    }
+    __syncthreads();
+    STAMP(5);
 
     // L/:393-419: population success rule.  In the merged stable sort of
     // [current | previous] an element of the current generation at sorted position i
@@ -274,6 +385,7 @@ __global__ __launch_bounds__(1024) void k_update(const UpdateArgs a)
         a.sc->k = isz;
         a.sc->generation = (uint32_t)(itr + 1);
     }
+    STAMP(6);
 
     // state back to memory, and the float images the sampling kernel reads:
     // V_f[q] = v_q, B_f[q] = M^(k-1-q) nj_q pc_q
@@ -308,9 +420,20 @@ __global__ __launch_bounds__(1024) void k_update(const UpdateArgs a)
             }
         }
     }
+    STAMP(7);
+#ifdef LMCMA_DIAG
+    if (threadIdx.x == 0) g_update_stamps[11] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 }  // namespace
+
+#ifdef LMCMA_DIAG
+extern "C" hipError_t lmcma_diag_update_stamps(unsigned long long *out16)
+{
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_update_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
 
 int recombine_num_blocks(int mu)
 {
@@ -361,14 +484,12 @@ hipError_t launch_update(hipStream_t s, const UpdateArgs &a)
 {
     if (a.m < 1 || a.m > LMCMA_HIP_MAX_VECTORS || a.N < 1 || a.N > 512 || a.n_partials < 1)
         return hipErrorInvalidValue;
-    const size_t fixed = (2 * LMCMA_HIP_MAX_VECTORS + 2 * (size_t)a.N) * sizeof(double) +
+    const size_t fixed = (4 * LMCMA_HIP_MAX_VECTORS + 2 * (size_t)a.N) * sizeof(double) +
                          (2 * LMCMA_HIP_MAX_VECTORS + 4) * sizeof(int);
     const size_t v_bytes = (size_t)a.m * a.N * sizeof(double);
     const bool v_lds = v_bytes + fixed <= 150 * 1024;
     const size_t lds = fixed + (v_lds ? v_bytes : 0);
-    int threads = 16 * a.m;
-    if (threads < 256) threads = 256;
-    threads = (threads + 63) & ~63;
+    const int threads = 1024;  // 16 lanes per direction vector (m <= 64), 8 lanes per coordinate in the mean
     const int emax = (a.N + 15) / 16;
 #define LMCMA_UPD(E)                                                             \
     return v_lds ? launch_update_t<E, true>(s, a, lds, threads) : launch_update_t<E, false>(s, a, lds, threads)
