@@ -91,6 +91,7 @@ struct lmcma_hip_ctx {
     int parity = 0, graph_parity = 0;
     bool warmed = false;
     unsigned long long *psr_accum = nullptr;
+    int psr_parts_n = 0;   // per-workgroup success-rule counts the last ranking left at the head of `keys`
     int32_t *perm = nullptr;
     uint64_t *keys = nullptr;
     float *xmean_f = nullptr, *V_f = nullptr, *B_f = nullptr, *lo_f = nullptr, *hi_f = nullptr;
@@ -102,6 +103,7 @@ struct lmcma_hip_ctx {
     OptScalars *opt = nullptr;
     float *scratch_rows = nullptr, *scratch_cost = nullptr, *scratch_terms = nullptr;
     double *xmean0 = nullptr;   // initial mean kept for lmcma_hip_opt_reset
+    void *arena = nullptr;      // the one allocation behind every buffer above
     double sigma0 = 1.0;
 
     void *grid = nullptr;
@@ -133,6 +135,32 @@ hipError_t dalloc(T **p, size_t count)
     if (e == hipSuccess) e = hipMemset(*p, 0, count * sizeof(T) + 16);
     return e;
 }
+
+// All buffers of a context that exist for its whole life come from one allocation: a
+// kernel that touches a dozen small buffers then needs a few address translations
+// instead of one per buffer (they share pages), which shortens every kernel's start.
+struct Arena {
+    std::vector<std::pair<void **, size_t>> req;
+    template <typename T>
+    void add(T **p, size_t count)
+    {
+        req.push_back({reinterpret_cast<void **>(p), (count * sizeof(T) + 16 + 255) & ~(size_t)255});
+    }
+    hipError_t commit(void **base)
+    {
+        size_t total = 0;
+        for (auto &r : req) total += r.second;
+        hipError_t e = hipMalloc(base, total);
+        if (e == hipSuccess) e = hipMemset(*base, 0, total);
+        if (e != hipSuccess) return e;
+        char *p = static_cast<char *>(*base);
+        for (auto &r : req) {
+            *r.first = p;
+            p += r.second;
+        }
+        return hipSuccess;
+    }
+};
 
 void drop_graph(lmcma_hip_ctx *c)
 {
@@ -242,37 +270,8 @@ int do_generate(lmcma_hip_ctx *c)
     return LMCMA_HIP_OK;
 }
 
-// with_recombine: the ranking launch also leaves the elite partial sums of the local
-// rows in block_partials (*rows_out rows); only on the ranking-by-counting path
-int do_select(lmcma_hip_ctx *c, bool with_recombine, int *rows_out)
+UpdateArgs update_args(const lmcma_hip_ctx *c, const double *partials, int n_partials)
 {
-    Timed tm(c, LMCMA_K_SELECT);
-    // the two sorted-cost buffers alternate: this generation's list is written beside last one's
-    c->parity ^= 1;
-    c->sorted_cost = c->sorted_buf[c->parity];
-    RecombineArgs rc{c->rows, c->ld, c->N, c->first, c->nloc, c->weights, c->mu, c->block_partials};
-    const bool fuse = with_recombine && c->have_weights && select_can_recombine(c->lambda);
-    HIP_TRY(launch_select(c->stream, c->cost_all, c->lambda, c->keys, c->sorted_cost, c->perm,
-                          c->opt_ready ? c->opt : nullptr, c->sorted_buf[c->parity ^ 1], c->psr_accum,
-                          fuse ? &rc : nullptr));
-    if (rows_out) *rows_out = fuse ? select_recombine_rows(c->first, c->nloc) : 0;
-    c->selected = true;
-    return LMCMA_HIP_OK;
-}
-
-// with_final: also reduce the block partials to partial_local (needed when the
-// partial sum leaves the context; k_update can add the block partials itself)
-int do_recombine(lmcma_hip_ctx *c, bool with_final)
-{
-    Timed tm(c, LMCMA_K_RECOMBINE);
-    HIP_TRY(launch_recombine(c->stream, c->rows, c->ld, c->N, c->first, c->nloc, c->perm, c->weights,
-                             c->mu, c->block_partials, with_final ? c->partial_local : nullptr));
-    return LMCMA_HIP_OK;
-}
-
-int do_update(lmcma_hip_ctx *c, const double *partials, int n_partials)
-{
-    Timed tm(c, LMCMA_K_UPDATE);
     UpdateArgs a{};
     a.opt = c->opt;
     a.sc = c->sc;
@@ -281,12 +280,59 @@ int do_update(lmcma_hip_ctx *c, const double *partials, int n_partials)
     a.n_partials = n_partials;
     a.sorted_cost = c->sorted_cost;
     a.psr_accum = c->psr_accum;
+    a.psr_parts = reinterpret_cast<const uint32_t *>(c->keys);
+    a.n_psr_parts = c->psr_parts_n;
     a.xmean = c->xmean; a.pc = c->pc;
     a.pc_arr = c->pc_arr; a.v_arr = c->v_arr;
     a.nj = c->nj; a.lj = c->lj;
     a.t = c->t; a.vec = c->vec; a.iterator = c->iterator;
     a.xmean_f = c->xmean_f; a.V_f = c->V_f; a.B_f = c->B_f;
-    HIP_TRY(launch_update(c->stream, a));
+    return a;
+}
+
+// with_recombine: the ranking launch also leaves the elite partial sums of the local rows
+// in block_partials (*rows_out rows); only populations ranked by counting
+int do_select(lmcma_hip_ctx *c, bool with_recombine, int *rows_out)
+{
+    Timed tm(c, LMCMA_K_SELECT);
+    // the two sorted-cost buffers alternate: this generation's list is written beside last one's
+    c->parity ^= 1;
+    c->sorted_cost = c->sorted_buf[c->parity];
+    RecombineArgs rc{c->rows, c->ld, c->N, c->first, c->nloc, c->weights, c->mu, c->block_partials};
+    const bool recombine = with_recombine && c->have_weights && select_by_counting(c->lambda);
+    SelectArgs a{};
+    a.cost_all = c->cost_all;
+    a.lambda = c->lambda;
+    a.keys_ws = c->keys;
+    a.sorted_cost = c->sorted_cost;
+    a.perm = c->perm;
+    a.opt = c->opt_ready ? c->opt : nullptr;
+    a.prev_sorted = c->sorted_buf[c->parity ^ 1];
+    a.psr_accum = c->psr_accum;
+    a.rc = recombine ? &rc : nullptr;
+    SelectResult res{};
+    HIP_TRY(launch_select(c->stream, a, &res));
+    c->psr_parts_n = res.psr_parts;
+    if (rows_out) *rows_out = res.partial_rows;
+    c->selected = true;
+    return LMCMA_HIP_OK;
+}
+
+// with_final: also reduce the block partials to partial_local (needed when the
+// partial sum leaves the context; the update can add the block partials itself)
+int do_recombine(lmcma_hip_ctx *c, bool with_final)
+{
+    Timed tm(c, LMCMA_K_RECOMBINE);
+    HIP_TRY(launch_recombine(c->stream, c->rows, c->ld, c->N, c->first, c->nloc, c->perm, c->weights,
+                             c->mu, c->block_partials, with_final ? c->partial_local : nullptr,
+                             update_threads(c->N, std::min(c->m, LMCMA_HIP_MAX_VECTORS))));
+    return LMCMA_HIP_OK;
+}
+
+int do_update(lmcma_hip_ctx *c, const double *partials, int n_partials)
+{
+    Timed tm(c, LMCMA_K_UPDATE);
+    HIP_TRY(launch_update(c->stream, update_args(c, partials, n_partials)));
     return LMCMA_HIP_OK;
 }
 
@@ -393,38 +439,41 @@ int lmcma_hip_create(const lmcma_hip_config *cfg, lmcma_hip_ctx **out)
         c->own_stream = true;
     }
     const size_t ld = c->ld, N = c->N, nloc = c->nloc, lam = c->lambda, m = c->m;
-    hipError_t e = hipSuccess;
+    // the small, hot buffers first; the candidate rows (the only large one) last
+    Arena ar;
+    ar.add(&c->opt, 1);
+    ar.add(&c->sc, 1);
+    ar.add(&c->psr_accum, 1);
+    ar.add(&c->t, m);
+    ar.add(&c->vec, m);
+    ar.add(&c->iterator, m);
+    ar.add(&c->nj, m);
+    ar.add(&c->lj, m);
+    ar.add(&c->xmean, N);
+    ar.add(&c->xmean0, N);
+    ar.add(&c->pc, N);
+    ar.add(&c->xmean_f, ld);
+    ar.add(&c->lo_f, ld);
+    ar.add(&c->hi_f, ld);
+    ar.add(&c->partial_local, N);
+    ar.add(&c->V_f, m * ld);
+    ar.add(&c->B_f, m * ld);
+    ar.add(&c->pc_arr, m * N);
+    ar.add(&c->v_arr, m * N);
+    ar.add(&c->weights, (size_t)c->mu);
+    ar.add(&c->cost_all, lam);
+    ar.add(&c->sorted_buf[0], lam + 4);
+    ar.add(&c->sorted_buf[1], lam + 4);
+    ar.add(&c->perm, lam);
+    ar.add(&c->keys, select_workspace_bytes(c->lambda) / sizeof(uint64_t) + 1);
+    ar.add(&c->partial_all, (size_t)kMaxPartials * N);
+    ar.add(&c->block_partials,
+           (size_t)std::max(recombine_num_blocks(c->mu), select_max_partial_rows(c->first, c->nloc)) * N);
+    ar.add(&c->terms, nloc * 3);
+    ar.add(&c->rows, nloc * ld);
+    hipError_t e = ar.commit(&c->arena);
     auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    A(dalloc(&c->rows, nloc * ld));
-    A(dalloc(&c->cost_all, lam));
-    A(dalloc(&c->terms, nloc * 3));
-    A(dalloc(&c->sorted_buf[0], lam + 4));
-    A(dalloc(&c->sorted_buf[1], lam + 4));
     c->sorted_cost = c->sorted_buf[0];
-    A(dalloc(&c->psr_accum, 1));
-    A(dalloc(&c->perm, lam));
-    A(dalloc(&c->keys, select_workspace_bytes(c->lambda) / sizeof(uint64_t) + 1));
-    A(dalloc(&c->xmean_f, ld));
-    A(dalloc(&c->V_f, m * ld));
-    A(dalloc(&c->B_f, m * ld));
-    A(dalloc(&c->lo_f, ld));
-    A(dalloc(&c->hi_f, ld));
-    A(dalloc(&c->sc, 1));
-    A(dalloc(&c->weights, (size_t)c->mu));
-    A(dalloc(&c->block_partials,
-             (size_t)std::max(recombine_num_blocks(c->mu), select_recombine_rows(c->first, c->nloc)) * N));
-    A(dalloc(&c->partial_local, N));
-    A(dalloc(&c->partial_all, (size_t)kMaxPartials * N));
-    A(dalloc(&c->xmean, N));
-    A(dalloc(&c->pc, N));
-    A(dalloc(&c->pc_arr, m * N));
-    A(dalloc(&c->v_arr, m * N));
-    A(dalloc(&c->nj, m));
-    A(dalloc(&c->lj, m));
-    A(dalloc(&c->t, m));
-    A(dalloc(&c->vec, m));
-    A(dalloc(&c->iterator, m));
-    A(dalloc(&c->opt, 1));
     if (e == hipSuccess) {
         // no bounds until set_bounds: -inf / +inf
         std::vector<float> lo(ld, -INFINITY), hi(ld, INFINITY);
@@ -448,11 +497,7 @@ int lmcma_hip_destroy(lmcma_hip_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graph(c);
     for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    void *bufs[] = {c->rows, c->zbuf, c->cost_all, c->terms, c->sorted_buf[0], c->sorted_buf[1], c->psr_accum, c->perm,
-                    c->keys, c->xmean_f, c->V_f, c->B_f, c->lo_f, c->hi_f, c->sc, c->weights,
-                    c->block_partials, c->partial_local, c->partial_all, c->xmean, c->pc, c->pc_arr,
-                    c->v_arr, c->nj, c->lj, c->t, c->vec, c->iterator, c->opt, c->scratch_rows,
-                    c->scratch_cost, c->scratch_terms, c->grid, c->xmean0};
+    void *bufs[] = {c->arena, c->zbuf, c->scratch_rows, c->scratch_cost, c->scratch_terms, c->grid};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -786,7 +831,6 @@ int lmcma_hip_opt_init(lmcma_hip_ctx *c, const double *xmean0, double sigma0)
     HIP_TRY(hipMemset(c->iterator, 0, m * sizeof(int32_t)));
     SampleScalars sc{(float)sigma0, 1.0f, 0, 0u};
     HIP_TRY(hipMemcpy(c->sc, &sc, sizeof(sc), hipMemcpyHostToDevice));
-    if (!c->xmean0) HIP_TRY(dalloc(&c->xmean0, (size_t)N));
     HIP_TRY(hipMemcpy(c->xmean0, xmean0, N * sizeof(double), hipMemcpyHostToDevice));
     c->sigma0 = sigma0;
     c->opt_ready = true;
@@ -875,7 +919,8 @@ int lmcma_hip_phase_rank(lmcma_hip_ctx *c)
     if (rc != LMCMA_HIP_OK) return rc;
     if (rows > 0) {
         Timed tm(c, LMCMA_K_RECOMBINE);
-        HIP_TRY(launch_recombine_final(c->stream, c->block_partials, rows, c->N, c->partial_local));
+        HIP_TRY(launch_recombine_final(c->stream, c->block_partials, rows, c->N, c->partial_local,
+                                       update_threads(c->N, std::min(c->m, LMCMA_HIP_MAX_VECTORS))));
         return LMCMA_HIP_OK;
     }
     return do_recombine(c, true);
@@ -957,11 +1002,13 @@ int lmcma_hip_synchronize(lmcma_hip_ctx *c)
 
 #ifdef LMCMA_DIAG
 hipError_t lmcma_diag_update_stamps(unsigned long long *out16);
-int lmcma_hip_diag_update_stamps(lmcma_hip_ctx *c, unsigned long long *out16)
+hipError_t lmcma_diag_rank_stamps(unsigned long long *out16);
+// which = 0: stamps of the stand-alone update kernel, 1: of the ranking kernel and its tail
+int lmcma_hip_diag_stamps(lmcma_hip_ctx *c, int which, unsigned long long *out16)
 {
     CTX_TRY(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(lmcma_diag_update_stamps(out16));
+    HIP_TRY(which ? lmcma_diag_rank_stamps(out16) : lmcma_diag_update_stamps(out16));
     return LMCMA_HIP_OK;
 }
 #endif

@@ -87,6 +87,29 @@ __device__ __forceinline__ float group_sum(float v)
     return v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+
+// ---- ranking keys --------------------------------------------------------------------
+// order-preserving image of a float cost in an unsigned word: a < b  <=>  key(a) < key(b)
+
+__device__ __forceinline__ uint32_t order_bits(float f)
+{
+    if (f != f) f = __builtin_inff();  // NaN ranks with +inf
+    f += 0.0f;                          // -0 compares equal to +0 in the reference
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float order_bits_inv(uint32_t k)
+{
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(u);
+}
+
 // ---- trajectory cost ---------------------------------------------------------------
 
 template <int D>

@@ -73,11 +73,10 @@ constexpr int kSortTile = 4096;
 constexpr int kRankCountMax = 16384;  // populations up to this size are ranked by counting
 int select_num_tiles(int lambda);
 size_t select_workspace_bytes(int lambda);
-// keys_ws: select_workspace_bytes(lambda) bytes.  When opt != nullptr and opt->itr > 0 the
-// kernels also add, for every candidate, the number of entries of prev_sorted (last
-// generation's ascending costs) below its cost into *psr_accum (population success rule).
-// rc != nullptr (only when select_can_recombine(lambda)): the same launch also writes the
-// elite partial sums of the local rows, select_recombine_rows(...) rows of block_partials.
+bool select_by_counting(int lambda);
+// rows of block_partials the counting path can write for a local candidate range
+int select_max_partial_rows(int first_candidate, int n_local);
+
 struct RecombineArgs {
     const float *rows;
     int ld, N, first_candidate, n_local;
@@ -85,22 +84,46 @@ struct RecombineArgs {
     int mu;
     double *block_partials;
 };
-bool select_can_recombine(int lambda);
-int select_recombine_rows(int first_candidate, int n_local);
-hipError_t launch_select(hipStream_t s, const float *cost_all, int lambda, uint64_t *keys_ws,
-                         float *sorted_cost, int32_t *perm, const OptScalars *opt,
-                         const float *prev_sorted, unsigned long long *psr_accum,
-                         const RecombineArgs *rc);
+
+// Ranking of all lambda costs (ascending, ties in candidate order) into sorted_cost / perm.
+// With opt, prev_sorted and psr_accum: when opt->itr > 0 the launch also counts, for every
+// candidate of this generation, the entries of prev_sorted (last generation's ascending
+// costs) below its cost (population success rule).  The sorting path adds the counts into
+// *psr_accum; the counting path (populations up to kRankCountMax) leaves one count per
+// workgroup in the first words of keys_ws (SelectResult::psr_parts of them).
+// rc (counting path only): the same launch adds the elite rows of the local candidates
+// into SelectResult::partial_rows rows of rc->block_partials.
+struct SelectArgs {
+    const float *cost_all;
+    int lambda;
+    uint64_t *keys_ws;             // select_workspace_bytes(lambda) bytes
+    float *sorted_cost;
+    int32_t *perm;
+    const OptScalars *opt;
+    const float *prev_sorted;
+    unsigned long long *psr_accum;
+    const RecombineArgs *rc;
+};
+struct SelectResult {
+    int partial_rows;   // rows of block_partials written (0: recombination not done)
+    int psr_parts;      // per-workgroup success-rule counts left in keys_ws (0: see psr_accum)
+};
+hipError_t launch_select(hipStream_t s, const SelectArgs &a, SelectResult *res);
+hipError_t launch_select_sort(hipStream_t s, const SelectArgs &a);
 
 constexpr int kRecombineRanksPerBlock = 32;
 int recombine_num_blocks(int mu);
 hipError_t launch_recombine(hipStream_t s, const float *rows, int ld, int N, int first_candidate,
                             int n_local, const int32_t *perm, const double *weights, int mu,
-                            double *block_partials, double *partial_local);
+                            double *block_partials, double *partial_local, int threads);
 
-// partial_local[N] = sum of the first `rows` rows of block_partials, in row order
+// partial_local[N] = sum of the first `rows` rows of block_partials, in the order in which a
+// workgroup of `threads` threads adds them (the update adds its partial rows in the same
+// order, so reducing first and updating from the one row gives the same bits)
 hipError_t launch_recombine_final(hipStream_t s, const double *block_partials, int rows, int N,
-                                  double *partial_local);
+                                  double *partial_local, int threads);
+// workgroup size the update uses for m direction vectors of N parameters
+int update_threads(int N, int m);
 
 struct UpdateArgs {
     OptScalars *opt;
@@ -109,8 +132,11 @@ struct UpdateArgs {
     const double *partials;  // [n_partials][N]
     int n_partials;
     const float *sorted_cost;   // [lambda] this generation, ascending
-    unsigned long long *psr_accum;  // sum over this generation's candidates of #{previous costs below it},
-                                    // left by the ranking kernels; read and zeroed by the update
+    // success rule: sum over this generation's candidates of #{previous costs below it} =
+    // *psr_accum (read and zeroed by the update) + psr_parts[0 .. n_psr_parts)
+    unsigned long long *psr_accum;
+    const uint32_t *psr_parts;
+    int n_psr_parts;
     double *xmean, *pc;         // [N]
     double *pc_arr, *v_arr;     // [m][N]
     double *nj, *lj;            // [m]

@@ -1,0 +1,406 @@
+// Ranking by counting for populations up to 16384, and the dispatcher of the ranking
+// paths.  Ascending order of all candidate costs, equal costs in candidate order.
+//
+// Replaces myqsort(lambda, arfitness, arindex, ...) (lmcma_path_planner/src/lmcma.cpp:91-104,
+// called at :315), the head of LMCMA::update (:316-326, weighted recombination) and the
+// rank sums of the population success rule (:393-413).
+//
+// One launch, every CU busy:
+//   * every workgroup stages all keys in LDS; 16 lanes share one candidate and count
+//     the keys below it (ties by candidate index), 4 keys per lane and LDS read; the sum
+//     over the 16 lanes is the candidate's rank, and candidate and cost are scattered to
+//     that position.  O(lambda^2) compares, but 16.7 M of them at lambda = 4096 is about
+//     a microsecond of the chip, where a one-workgroup sorting network occupies a single
+//     CU for tens of microseconds;
+//   * the same 16 lanes find the number of last generation's costs below the candidate
+//     with a 16-way search of last generation's ascending list (also staged in LDS); the
+//     workgroup's total goes to psr_parts[workgroup];
+//   * the workgroup adds weights[rank] * row over its own elite candidates, candidates
+//     in index order, and writes one row of block_partials.  The reference adds the
+//     elites in rank order; grouping by candidate index changes fp64 rounding only.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "update_body.hpp"
+
+namespace lmcma {
+
+namespace {
+
+struct RankArgs {
+    const float *cost;
+    int lambda;
+    float *sorted_cost;
+    int32_t *perm;
+    const OptScalars *opt;       // with prev_sorted: success-rule count when opt->itr > 0
+    const float *prev_sorted;
+    uint32_t *psr_parts;         // [gridDim.x]
+    const float *rows;           // recombination (weights == nullptr: none)
+    int ld, N, first_candidate, n_local;
+    const double *weights;
+    int mu;
+    int weights_in_lds;
+    double *block_partials;      // [workgroups holding local candidates][N]
+    int first_block;
+};
+
+__device__ __forceinline__ uint32_t row16_sum_u32(uint32_t v)
+{
+    v += dpp_mov<0x128>(v);
+    v += dpp_mov<0x124>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0xB1>(v);
+    return v;
+}
+
+// LDS layout (doubles first): recombination slots, candidate weights, weight table, then
+// keys, previous list, per-wave counts
+size_t rank_lds_bytes(int TB, int lambda, int N, int mu, bool psr, bool recombine, bool weights_in_lds)
+{
+    const size_t lpad = ((size_t)lambda + 255) & ~(size_t)255;
+    size_t b = 0;
+    if (recombine)
+        b += ((size_t)(TB > N ? TB : N) + TB / 16 + (weights_in_lds ? (((size_t)mu + 1) & ~(size_t)1) : 0)) * sizeof(double);
+    b += lpad * sizeof(uint32_t);
+    if (psr) b += lpad * sizeof(float);
+    b += 16 * sizeof(uint32_t);
+    return b;
+}
+
+#ifdef LMCMA_DIAG
+#define RANK_STAMP(i) st[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define RANK_STAMP(i)
+#endif
+
+template <int TB>
+__global__ __launch_bounds__(TB) void k_rank(const RankArgs r)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+    constexpr int CPB = TB / 16;  // candidates per workgroup
+    const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
+    const int lambda = r.lambda, N = r.N;
+    const int lpad = (lambda + 255) & ~255;  // keys padded to whole rounds of 256
+    const bool recombine = r.weights != nullptr;
+    const bool psr = r.prev_sorted != nullptr && r.opt != nullptr && r.opt->itr > 0;  // uniform over the grid
+    const bool wlds = recombine && r.weights_in_lds;
+
+    double *s_part = s_dyn;                                                   // [rg][N]
+    double *s_w = s_part + (recombine ? (TB > N ? TB : N) : 0);               // [CPB] weight of each candidate
+    double *s_weights = s_w + (recombine ? CPB : 0);                          // [mu] when staged
+    uint32_t *s_key = reinterpret_cast<uint32_t *>(s_weights + (wlds ? ((r.mu + 1) & ~1) : 0));
+    float *s_prev = reinterpret_cast<float *>(s_key + lpad);                  // [lpad] when psr
+    uint32_t *s_below = reinterpret_cast<uint32_t *>(s_prev + (psr ? lpad : 0));  // [TB / 64]
+#ifdef LMCMA_DIAG
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    RANK_STAMP(0);
+
+    // ---- stage keys, last generation's list and the weights.  The costs were written by
+    // the previous kernel, so the first touch of every line misses this XCD's L2: all loads
+    // of the first batch (4 x 16 bytes per lane and array, and the first rows of the
+    // recombination) are issued before anything waits for one of them.
+    const int n4 = lpad >> 2, live4 = (lambda + 3) >> 2, n2 = (r.mu + 1) >> 1;
+    const float4 *ksrc = reinterpret_cast<const float4 *>(r.cost);  // padded to a multiple of 16 bytes
+    const float4 *psrc = reinterpret_cast<const float4 *>(r.prev_sorted);
+    const double2 *wsrc = reinterpret_cast<const double2 *>(r.weights);
+    uint4 *kdst = reinterpret_cast<uint4 *>(s_key);
+    float4 *pdst = reinterpret_cast<float4 *>(s_prev);
+    double2 *wdst = reinterpret_cast<double2 *>(s_weights);
+    const int c0 = blockIdx.x * CPB;
+    const RowSumPlan pl = row_sum_plan(N, TB);
+    const int ch = (CPB + pl.rg - 1) / pl.rg;  // candidates per row group
+    const int rgi = tid / pl.cw, n0 = tid % pl.cw;
+    {
+        float4 kc[4], pv[4];
+        double2 wv[4];
+        float xr0[8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tid + u * TB;
+            kc[u] = ksrc[t < live4 ? t : live4 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tid + u * TB;
+            pv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (psr) pv[u] = psrc[t < live4 ? t : live4 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tid + u * TB;
+            wv[u] = make_double2(0.0, 0.0);
+            if (wlds) wv[u] = wsrc[t < n2 ? t : n2 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            xr0[u] = 0.f;
+            if (recombine) {
+                int local = c0 + (rgi < pl.rg ? rgi : 0) * ch + u - r.first_candidate;
+                local = local < 0 ? 0 : (local >= r.n_local ? r.n_local - 1 : local);
+                xr0[u] = r.rows[(size_t)local * r.ld + (n0 < N ? n0 : N - 1)];
+            }
+        }
+        asm volatile("" ::: "memory");  // the loads above stay above: none is sunk into a branch below
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tid + u * TB, j = 4 * t;
+            if (t < n4) {
+                uint4 k;  // padding (~0) ranks after every cost
+                k.x = j < lambda ? order_bits(kc[u].x) : ~0u;
+                k.y = j + 1 < lambda ? order_bits(kc[u].y) : ~0u;
+                k.z = j + 2 < lambda ? order_bits(kc[u].z) : ~0u;
+                k.w = j + 3 < lambda ? order_bits(kc[u].w) : ~0u;
+                kdst[t] = k;
+            }
+            if (psr && t < live4) pdst[t] = pv[u];
+            if (wlds && t < n2) wdst[t] = wv[u];
+        }
+        // populations beyond 16 lanes x 4 x TB: the rest, batch by batch
+        for (int t0 = tid + 4 * TB; t0 < n4; t0 += TB) {
+            const int j = 4 * t0;
+            const float4 c = ksrc[t0 < live4 ? t0 : live4 - 1];
+            uint4 k;
+            k.x = j < lambda ? order_bits(c.x) : ~0u;
+            k.y = j + 1 < lambda ? order_bits(c.y) : ~0u;
+            k.z = j + 2 < lambda ? order_bits(c.z) : ~0u;
+            k.w = j + 3 < lambda ? order_bits(c.w) : ~0u;
+            kdst[t0] = k;
+            if (psr && t0 < live4) pdst[t0] = psrc[t0];
+        }
+        if (wlds)
+            for (int t0 = tid + 4 * TB; t0 < n2; t0 += TB) wdst[t0] = wsrc[t0];
+        __syncthreads();
+        RANK_STAMP(1);
+
+        // ---- count the keys below each candidate's own.  A wave owns four candidates; every
+        // lane reads four keys of its own per round (no LDS word is read twice by a wave) and
+        // compares them with the wave's four candidates.
+        const int w4 = (tid >> 6) << 2;  // first of this wave's candidates, within the workgroup
+        uint32_t mine_q[4], cq[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mine_q[q] = __builtin_amdgcn_readfirstlane(s_key[c0 + w4 + q]);  // < lpad
+        {
+            const int r0 = c0 >> 8, rounds = lpad >> 8;  // CPB divides 256: one round holds the whole workgroup
+            const uint4 *k4 = reinterpret_cast<const uint4 *>(s_key) + wl;  // round t: keys 256 t + 4 wl ..
+            // rounds before the candidates' own: every key there has a lower index, so ties count
+#pragma unroll 2
+            for (int t = 0; t < r0; ++t) {
+                const uint4 a = k4[64 * t];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    cq[q] += (a.x <= mine_q[q]) + (a.y <= mine_q[q]) + (a.z <= mine_q[q]) + (a.w <= mine_q[q]);
+            }
+            {
+                const uint4 a = k4[64 * r0];
+                const int j = 256 * r0 + 4 * wl;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t mq = mine_q[q];
+                    const int iq = c0 + w4 + q;
+                    cq[q] += (a.x < mq || (a.x == mq && j < iq));
+                    cq[q] += (a.y < mq || (a.y == mq && j + 1 < iq));
+                    cq[q] += (a.z < mq || (a.z == mq && j + 2 < iq));
+                    cq[q] += (a.w < mq || (a.w == mq && j + 3 < iq));
+                }
+            }
+#pragma unroll 2
+            for (int t = r0 + 1; t < rounds; ++t) {
+                const uint4 a = k4[64 * t];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    cq[q] += (a.x < mine_q[q]) + (a.y < mine_q[q]) + (a.z < mine_q[q]) + (a.w < mine_q[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t v = row16_sum_u32(cq[q]);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            cq[q] = v;
+        }
+        // the 16 lanes of group g carry on with candidate c0 + g
+        const int gq = grp & 3;
+        const int rank = (int)(gq == 0 ? cq[0] : gq == 1 ? cq[1] : gq == 2 ? cq[2] : cq[3]);
+        const uint32_t mine = gq == 0 ? mine_q[0] : gq == 1 ? mine_q[1] : gq == 2 ? mine_q[2] : mine_q[3];
+        const int i = c0 + grp;
+        const bool live = i < lambda;
+        const float value = order_bits_inv(mine);  // NaN -> +inf, -0 -> +0 like the keys
+        RANK_STAMP(2);
+
+        // ---- success rule: number of last generation's costs below this one, 16-way search
+        uint32_t below = 0;
+        if (psr) {
+            int lo = 0, len = lambda;  // the answer lies in [lo, lo + len]
+            while (len > 0) {
+                const int chunk = (len + 15) >> 4;
+                const int p = lo + (lane + 1) * chunk - 1;
+                const bool lt = p < lo + len && s_prev[p] < value;
+                const unsigned long long mask = __ballot(lt);
+                const int q = __popcll((mask >> (tid & 48)) & 0xFFFFull);  // probes below, of this group's 16
+                const int end = lo + len;
+                lo += q * chunk;
+                len = chunk - 1 < end - lo ? chunk - 1 : end - lo;
+            }
+            below = (live && lane == 0) ? (uint32_t)lo : 0u;
+        }
+        // the four groups of a wave add their counts: lanes 0, 16, 32, 48 hold them
+        below += __shfl_xor(below, 16, 64);
+        below += __shfl_xor(below, 32, 64);
+        if (lane == 0) {
+            if (live) {
+                r.sorted_cost[rank] = value;
+                r.perm[rank] = i;
+            }
+            if (wl == 0) s_below[tid >> 6] = below;
+            if (recombine) {
+                const int local = i - r.first_candidate;
+                const bool elite = live && rank < r.mu && local >= 0 && local < r.n_local;
+                s_w[grp] = elite ? (wlds ? s_weights[rank] : r.weights[rank]) : 0.0;
+            }
+        }
+        __syncthreads();
+        RANK_STAMP(3);
+        if (tid == 0) {
+            uint32_t total = 0;
+#pragma unroll
+            for (int w = 0; w < TB / 64; ++w) total += s_below[w];
+            r.psr_parts[blockIdx.x] = total;
+        }
+
+        // ---- elite rows of this workgroup, candidates in index order
+        if (recombine) {
+            const bool has_local = c0 + CPB > r.first_candidate && c0 < r.first_candidate + r.n_local;
+            if (rgi < pl.rg) {
+                for (int n = n0; n < N; n += pl.cw) {
+                    double acc = 0.0;
+                    for (int u0 = 0; u0 < ch; u0 += 8) {
+                        float x[8];
+                        if (u0 == 0 && n == n0) {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) x[u] = xr0[u];
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                int local = c0 + rgi * ch + u0 + u - r.first_candidate;
+                                local = local < 0 ? 0 : (local >= r.n_local ? r.n_local - 1 : local);
+                                x[u] = r.rows[(size_t)local * r.ld + n];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int c = rgi * ch + u0 + u;
+                            const double w = (u0 + u < ch && c < CPB) ? s_w[c] : 0.0;
+                            if (w != 0.0) acc += w * (double)x[u];
+                        }
+                    }
+                    s_part[rgi * N + n] = acc;
+                }
+            }
+            __syncthreads();
+            if (has_local) {
+                double *dst = r.block_partials + (size_t)((int)blockIdx.x - r.first_block) * N;
+                for (int n = tid; n < N; n += TB) dst[n] = row_sums_total(s_part, N, n, pl.rg);
+            }
+        }
+    }
+#ifdef LMCMA_DIAG
+    RANK_STAMP(4);
+    if (tid == 0 && blockIdx.x == gridDim.x - 1)
+        for (int q = 0; q < 5; ++q) g_update_stamps[8 + q] = st[q];
+#endif
+}
+
+template <int TB>
+hipError_t launch_rank_t(hipStream_t s, const RankArgs &r, int blocks, size_t lds)
+{
+    static size_t configured = 48 * 1024;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rank<TB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL((k_rank<TB>), dim3(blocks), dim3(TB), lds, s, r);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+#ifdef LMCMA_DIAG
+extern "C" hipError_t lmcma_diag_rank_stamps(unsigned long long *out16)
+{
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_update_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
+
+bool select_by_counting(int lambda)
+{
+    return lambda <= kRankCountMax && getenv("LMCMA_HIP_SELECT_SORT") == nullptr;
+}
+
+// candidates per workgroup of the counting path: 16 lanes each
+int select_candidates_per_block(int lambda)
+{
+    int threads = 256;
+    if (const char *f = getenv("LMCMA_HIP_RANK_THREADS")) {
+        const int v = atoi(f);
+        if (v == 256 || v == 512 || v == 1024) threads = v;
+    }
+    return threads / 16;
+}
+
+int select_max_partial_rows(int first_candidate, int n_local)
+{
+    const int cpb = 16;  // the smallest workgroup of the counting path ranks 16 candidates
+    return (first_candidate + n_local + cpb - 1) / cpb - first_candidate / cpb;
+}
+
+hipError_t launch_select(hipStream_t s, const SelectArgs &a, SelectResult *res)
+{
+    SelectResult out{};
+    if (res) *res = out;
+    const int lambda = a.lambda;
+    if (lambda <= 0) return hipErrorInvalidValue;
+    if (!select_by_counting(lambda)) return launch_select_sort(s, a);
+
+    const OptScalars *opt = (a.prev_sorted && a.psr_accum) ? a.opt : nullptr;
+    RankArgs r{};
+    r.cost = a.cost_all;
+    r.lambda = lambda;
+    r.sorted_cost = a.sorted_cost;
+    r.perm = a.perm;
+    r.opt = opt;
+    r.prev_sorted = opt ? a.prev_sorted : nullptr;
+    r.psr_parts = reinterpret_cast<uint32_t *>(a.keys_ws);
+    const RecombineArgs *rc = a.rc;
+    r.ld = 4;
+    r.N = 4;
+    const int cpb = select_candidates_per_block(lambda);
+    const int TB = cpb * 16;
+    const int blocks = (lambda + cpb - 1) / cpb;
+    int rows = 0;
+    if (rc) {
+        r.rows = rc->rows; r.ld = rc->ld; r.N = rc->N;
+        r.first_candidate = rc->first_candidate; r.n_local = rc->n_local;
+        r.weights = rc->weights; r.mu = rc->mu;
+        r.block_partials = rc->block_partials;
+        r.first_block = rc->first_candidate / cpb;
+        rows = (rc->first_candidate + rc->n_local + cpb - 1) / cpb - r.first_block;
+    }
+    const bool psr = opt != nullptr;
+    size_t lds = rank_lds_bytes(TB, lambda, r.N, r.mu, psr, rc != nullptr, true);
+    r.weights_in_lds = rc && lds <= 150 * 1024;
+    if (!r.weights_in_lds) lds = rank_lds_bytes(TB, lambda, r.N, r.mu, psr, rc != nullptr, false);
+    hipError_t e;
+    if (TB == 256) e = launch_rank_t<256>(s, r, blocks, lds);
+    else if (TB == 512) e = launch_rank_t<512>(s, r, blocks, lds);
+    else e = launch_rank_t<1024>(s, r, blocks, lds);
+    out.partial_rows = rows;
+    out.psr_parts = opt ? blocks : 0;
+    if (res) *res = out;
+    return e;
+}
+
+}  // namespace lmcma

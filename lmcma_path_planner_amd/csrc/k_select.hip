@@ -7,15 +7,8 @@
 // word (order-preserving image of the float cost << 32) | candidate index, so keys
 // are distinct and any correct sort yields that same permutation.
 //
-// Populations up to 16384 are ranked by counting, which uses every CU: block
-// (it, jt) counts, for its 256 candidates, the keys of j-tile jt that are below the
-// candidate's own key (the j-tile is read from LDS at one address per step, a
-// broadcast); k_rank_scatter adds the per-tile counts, which is the candidate's
-// rank, and scatters candidate and cost to that position.  O(lambda^2) compares,
-// but 16.7 M of them at lambda = 4096 is ~1 us of the chip, where a one-workgroup
-// sorting network occupies a single CU for tens of us.
-//
-// Larger populations fall back to sorted tiles plus a merge:
+// Populations up to 16384 are ranked by counting (k_rank.hip), which uses every CU.
+// Larger populations are ranked here, by sorted tiles plus a merge:
 // Step 1: each workgroup of 512 threads sorts one tile of 4096 keys with a bitonic
 // network, 8 keys per thread.  Element i lives in thread i / 8, register i % 8, so
 // of the 78 compare-exchange rounds 33 stay inside a thread, 39 cross lanes of one
@@ -26,7 +19,7 @@
 // tile: that sum is its global rank, and it scatters itself there.
 #include <stdlib.h>
 
-#include "device_types.hpp"
+#include "device_funcs.hpp"
 
 namespace lmcma {
 
@@ -35,20 +28,6 @@ namespace {
 constexpr int kThreads = 512;
 constexpr int kPerThread = kSortTile / kThreads;  // 8
 static_assert(kPerThread == 8, "the in-thread rounds below are written for 8 keys per thread");
-
-__device__ __forceinline__ uint32_t order_bits(float f)
-{
-    if (f != f) f = __builtin_inff();  // NaN ranks with +inf
-    f += 0.0f;                          // -0 compares equal to +0 in the reference
-    const uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-__device__ __forceinline__ float order_bits_inv(uint32_t k)
-{
-    const uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
-    return __uint_as_float(u);
-}
 
 // after the call a <= b when up, a >= b otherwise
 __device__ __forceinline__ void cx(uint64_t &a, uint64_t &b, bool up)
@@ -170,27 +149,6 @@ __global__ __launch_bounds__(256) void k_merge_rank(const uint64_t *__restrict__
     perm[rank] = (int32_t)(uint32_t)key;
 }
 
-// ---- rank by counting ----------------------------------------------------------------
-
-template <int JT>
-__global__ __launch_bounds__(256) void k_rank_count(const float *__restrict__ cost, int lambda,
-                                                    uint32_t *__restrict__ counts /* [njt][lambda] */)
-{
-    __shared__ uint64_t jkeys[JT];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int j0 = blockIdx.y * JT;
-    for (int t = threadIdx.x; t < JT; t += 256) {
-        const int j = j0 + t;
-        jkeys[t] = (j < lambda) ? (((uint64_t)order_bits(cost[j]) << 32) | (uint32_t)j) : ~0ull;
-    }
-    const uint64_t mine = (i < lambda) ? (((uint64_t)order_bits(cost[i]) << 32) | (uint32_t)i) : 0ull;
-    __syncthreads();
-    uint32_t below = 0;
-#pragma unroll 16
-    for (int t = 0; t < JT; ++t) below += (jkeys[t] < mine) ? 1u : 0u;
-    if (i < lambda) counts[(size_t)blockIdx.y * lambda + i] = below;
-}
-
 // block-wide sum of one 64-bit count per thread, added to *accum by one atomic
 __device__ __forceinline__ void block_add_u64(unsigned long long v, unsigned long long *accum,
                                               unsigned long long *s_wave /* [4] */)
@@ -216,99 +174,6 @@ __device__ __forceinline__ int count_below(const float *prev, int n, float c)
     return lo;
 }
 
-// Second half of ranking by counting, 64 candidates per block:
-//   rank = sum of the per-tile counts; the candidate and its cost go to that position;
-//   the population-success-rule count against last generation's list (staged in LDS);
-//   and, when weights are given, the block's share of the elite recombination
-//   (lmcma.cpp:321-326): sum over its own candidates with rank < mu of
-//   weights[rank] * row, candidates in index order, as one row of block_partials.
-// The reference adds the elites in rank order; this adds the same terms grouped by
-// candidate index, which changes fp64 rounding only.
-constexpr int kFinishCands = 64;
-
-__global__ __launch_bounds__(256) void k_rank_finish(const float *__restrict__ cost, int lambda,
-                                                     const uint32_t *__restrict__ counts, int njt,
-                                                     float *__restrict__ sorted_cost,
-                                                     int32_t *__restrict__ perm,
-                                                     const OptScalars *__restrict__ opt,
-                                                     const float *__restrict__ prev_sorted,
-                                                     unsigned long long *__restrict__ psr_accum,
-                                                     const float *__restrict__ rows, int ld, int N,
-                                                     int first_candidate, int n_local,
-                                                     const double *__restrict__ weights, int mu,
-                                                     double *__restrict__ block_partials, int first_block)
-{
-    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-    // carve: recombination slots [nslots][ld] doubles | ranks [64] ints | previous list [lambda] floats
-    const int nq = ld >> 2;
-    const int nslots = weights ? 256 / nq : 0;
-    double *s_part = s_dyn;
-    int *s_rank = reinterpret_cast<int *>(s_dyn + (size_t)nslots * ld);
-    float *s_prev = reinterpret_cast<float *>(s_rank + kFinishCands);
-    __shared__ unsigned long long s_wave[4];
-
-    const bool psr = opt != nullptr && opt->itr > 0;  // uniform over the grid
-    if (psr) {
-        const float4 *src = reinterpret_cast<const float4 *>(prev_sorted);
-        float4 *dst = reinterpret_cast<float4 *>(s_prev);
-        for (int t = threadIdx.x; t < ((lambda + 3) >> 2); t += 256) dst[t] = src[t];
-    }
-    const int c0 = blockIdx.x * kFinishCands;
-    // four threads per candidate add the per-tile counts
-    {
-        const int t = threadIdx.x >> 2, part = threadIdx.x & 3;
-        const int i = c0 + t;
-        uint32_t rank = 0;
-        if (i < lambda)
-            for (int jt = part; jt < njt; jt += 4) rank += counts[(size_t)jt * lambda + i];
-        rank += __shfl_xor(rank, 1, 64);
-        rank += __shfl_xor(rank, 2, 64);
-        if (part == 0) s_rank[t] = (i < lambda) ? (int)rank : 0x7fffffff;
-    }
-    __syncthreads();
-    unsigned long long below = 0ull;
-    if (threadIdx.x < kFinishCands) {
-        const int i = c0 + threadIdx.x;
-        if (i < lambda) {
-            const int rank = s_rank[threadIdx.x];
-            const float c = order_bits_inv(order_bits(cost[i]));  // NaN -> +inf, -0 -> +0 like the keys
-            sorted_cost[rank] = c;
-            perm[rank] = i;
-            if (psr) below = (unsigned long long)count_below(s_prev, lambda, c);
-        }
-    }
-    if (weights) {
-        const int slot = threadIdx.x / nq, q = threadIdx.x % nq;
-        if (slot < nslots) {
-            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-            for (int t = slot; t < kFinishCands; t += nslots) {
-                const int rank = s_rank[t];
-                const int local = c0 + t - first_candidate;
-                if (rank < mu && local >= 0 && local < n_local) {
-                    const float4 x = reinterpret_cast<const float4 *>(rows + (size_t)local * ld)[q];
-                    const double w = weights[rank];
-                    a0 += w * (double)x.x; a1 += w * (double)x.y;
-                    a2 += w * (double)x.z; a3 += w * (double)x.w;
-                }
-            }
-            double *dst = s_part + (size_t)slot * ld + 4 * q;
-            dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
-        }
-    }
-    if (psr) block_add_u64(below, psr_accum, s_wave);  // contains a barrier
-    else __syncthreads();
-    if (weights) {
-        const int lb = (int)blockIdx.x - first_block;  // blocks without local candidates write nothing
-        const bool has_local = c0 + kFinishCands > first_candidate && c0 < first_candidate + n_local;
-        if (has_local)
-            for (int n = threadIdx.x; n < N; n += 256) {
-                double acc = 0.0;
-                for (int sl = 0; sl < nslots; ++sl) acc += s_part[(size_t)sl * ld + n];
-                block_partials[(size_t)lb * N + n] = acc;
-            }
-    }
-}
-
 // the same count for the sorting paths: one thread per candidate, list in global memory
 __global__ __launch_bounds__(256) void k_psr_count(const float *__restrict__ cost, int lambda,
                                                    const OptScalars *__restrict__ opt,
@@ -327,79 +192,31 @@ __global__ __launch_bounds__(256) void k_psr_count(const float *__restrict__ cos
 
 size_t select_workspace_bytes(int lambda)
 {
-    const size_t tiles = (size_t)select_num_tiles(lambda) * kSortTile * sizeof(uint64_t);
-    if (lambda > kRankCountMax) return tiles;
-    const int jt = lambda <= 4096 ? 128 : 512;
-    const size_t counts = (size_t)((lambda + jt - 1) / jt) * lambda * sizeof(uint32_t);
-    return counts > tiles ? counts : tiles;
+    // tiles of the sorting path; the counting path keeps its per-workgroup counts in the same buffer
+    return (size_t)select_num_tiles(lambda) * kSortTile * sizeof(uint64_t);
 }
 
 int select_num_tiles(int lambda) { return (lambda + kSortTile - 1) / kSortTile; }
 
-bool select_can_recombine(int lambda)
+hipError_t launch_select_sort(hipStream_t s, const SelectArgs &a)
 {
-    return lambda <= kRankCountMax && getenv("LMCMA_HIP_SELECT_SORT") == nullptr;
-}
-
-int select_recombine_rows(int first_candidate, int n_local)
-{
-    return (first_candidate + n_local + kFinishCands - 1) / kFinishCands - first_candidate / kFinishCands;
-}
-
-hipError_t launch_select(hipStream_t s, const float *cost_all, int lambda, uint64_t *keys_ws,
-                         float *sorted_cost, int32_t *perm, const OptScalars *opt,
-                         const float *prev_sorted, unsigned long long *psr_accum,
-                         const RecombineArgs *rc)
-{
-    if (lambda <= 0) return hipErrorInvalidValue;
-    if (!prev_sorted || !psr_accum) opt = nullptr;
-    if (lambda <= kRankCountMax && getenv("LMCMA_HIP_SELECT_SORT") == nullptr) {
-        uint32_t *counts = reinterpret_cast<uint32_t *>(keys_ws);
-        const int it = (lambda + 255) / 256;
-        int njt;
-        if (lambda <= 4096) {
-            njt = (lambda + 127) / 128;
-            hipLaunchKernelGGL(k_rank_count<128>, dim3(it, njt), dim3(256), 0, s, cost_all, lambda, counts);
-        } else {
-            njt = (lambda + 511) / 512;
-            hipLaunchKernelGGL(k_rank_count<512>, dim3(it, njt), dim3(256), 0, s, cost_all, lambda, counts);
-        }
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        const int nblocks = (lambda + kFinishCands - 1) / kFinishCands;
-        const int nslots = rc ? 256 / (rc->ld >> 2) : 0;
-        const size_t lds = (rc ? (size_t)nslots * rc->ld * sizeof(double) : 0) + kFinishCands * sizeof(int) +
-                           (opt ? (size_t)((lambda + 3) & ~3) * sizeof(float) : 0);
-        static size_t configured = 48 * 1024;
-        if (lds > configured) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rank_finish),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            configured = lds;
-        }
-        hipLaunchKernelGGL(k_rank_finish, dim3(nblocks), dim3(256), lds, s, cost_all, lambda, counts, njt,
-                           sorted_cost, perm, opt, prev_sorted, psr_accum, rc ? rc->rows : nullptr,
-                           rc ? rc->ld : 4, rc ? rc->N : 0, rc ? rc->first_candidate : 0, rc ? rc->n_local : 0,
-                           rc ? rc->weights : nullptr, rc ? rc->mu : 0, rc ? rc->block_partials : nullptr,
-                           rc ? rc->first_candidate / kFinishCands : 0);
-        return hipGetLastError();
-    }
-    if (rc) return hipErrorInvalidValue;  // the fused recombination exists only on the counting path
+    const int lambda = a.lambda;
+    const OptScalars *opt = (a.prev_sorted && a.psr_accum) ? a.opt : nullptr;
     const int ntiles = select_num_tiles(lambda);
-    hipLaunchKernelGGL(k_sort_tiles, dim3(ntiles), dim3(kThreads), 0, s, cost_all, lambda, keys_ws,
-                       sorted_cost, perm, ntiles == 1 ? 1 : 0);
+    hipLaunchKernelGGL(k_sort_tiles, dim3(ntiles), dim3(kThreads), 0, s, a.cost_all, lambda, a.keys_ws,
+                       a.sorted_cost, a.perm, ntiles == 1 ? 1 : 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ntiles > 1) {
         const int total = ntiles * kSortTile;
-        hipLaunchKernelGGL(k_merge_rank, dim3((total + 255) / 256), dim3(256), 0, s, keys_ws, ntiles,
-                           sorted_cost, perm);
+        hipLaunchKernelGGL(k_merge_rank, dim3((total + 255) / 256), dim3(256), 0, s, a.keys_ws, ntiles,
+                           a.sorted_cost, a.perm);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     if (opt) {
-        hipLaunchKernelGGL(k_psr_count, dim3((lambda + 255) / 256), dim3(256), 0, s, cost_all, lambda, opt,
-                           prev_sorted, psr_accum);
+        hipLaunchKernelGGL(k_psr_count, dim3((lambda + 255) / 256), dim3(256), 0, s, a.cost_all, lambda, opt,
+                           a.prev_sorted, a.psr_accum);
         e = hipGetLastError();
     }
     return e;

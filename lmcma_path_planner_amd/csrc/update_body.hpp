@@ -1,0 +1,499 @@
+// The LM-CMA state update as a device function of one workgroup (fp64), and the
+// fixed-order row sums it shares with the ranking kernels.
+//
+// Replaces LMCMA::update (lmcma_path_planner/src/lmcma.cpp:313-424) and invAz
+// (:449-463); the citations L/:a-b below are lines of that file.
+#pragma once
+
+#include "device_funcs.hpp"
+
+namespace lmcma {
+
+// ---- rows of doubles added in a fixed order by one workgroup ------------------------
+// Thread (r, n) adds rows r, r + rg, r + 2 rg, ... of column n (rg row groups of cw
+// threads each); the rg partial sums of a column are then added in group order.  The
+// tree depends on (blockDim, N, count) only.
+
+struct RowSumPlan {
+    int cw;  // threads per row group, at most the workgroup
+    int rg;  // row groups
+};
+
+__device__ __forceinline__ RowSumPlan row_sum_plan(int N, int T)
+{
+    int cw = (N + 63) & ~63;
+    if (cw > T) cw = T;
+    return {cw, T / cw};
+}
+
+// The same with two adjacent columns per thread (16-byte loads), for even N.
+__device__ __forceinline__ RowSumPlan row_sum_plan2(int N, int T)
+{
+    int cw = ((N >> 1) + 63) & ~63;
+    if (cw > T) cw = T;
+    return {cw, T / cw};
+}
+
+// first half: partial sums to s_red[r * N + n]; the caller puts a barrier after it.
+// The rows were written by the previous kernel, so every first touch misses this XCD's
+// L2, and one workgroup has to keep many wide loads in flight to read them at any speed:
+// 16 bytes per lane (even N; a single workgroup reads such data about twice as fast with
+// 16-byte as with 8-byte loads) and up to 16 loads per thread at once.
+__device__ __forceinline__ void row_sums_to_lds(const double *src, int count, int N, double *s_red)
+{
+    constexpr int kBatch = 16;
+    if ((N & 1) == 0) {
+        const RowSumPlan pl = row_sum_plan2(N, (int)blockDim.x);
+        // cw is a multiple of 64 (or the whole workgroup), so r is the same in every lane of a wave
+        const int r = __builtin_amdgcn_readfirstlane((int)threadIdx.x / pl.cw);
+        const int n0 = 2 * ((int)threadIdx.x % pl.cw);
+        if (r >= pl.rg) return;
+        for (int n = n0; n < N; n += 2 * pl.cw) {
+            double a0 = 0.0, a1 = 0.0;
+            for (int b0 = r; b0 < count; b0 += kBatch * pl.rg) {
+                double2 v[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int b = b0 + u * pl.rg;  // wave-uniform
+                    v[u] = make_double2(0.0, 0.0);
+                    if (b < count) v[u] = *reinterpret_cast<const double2 *>(src + (size_t)b * N + n);
+                }
+                asm volatile("" ::: "memory");  // all loads of the batch are issued before the first add
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u)
+                    if (b0 + u * pl.rg < count) {
+                        a0 += v[u].x;
+                        a1 += v[u].y;
+                    }
+            }
+            s_red[r * N + n] = a0;
+            s_red[r * N + n + 1] = a1;
+        }
+        return;
+    }
+    const RowSumPlan pl = row_sum_plan(N, (int)blockDim.x);
+    const int r = __builtin_amdgcn_readfirstlane((int)threadIdx.x / pl.cw);
+    const int n0 = (int)threadIdx.x % pl.cw;
+    if (r >= pl.rg) return;
+    for (int n = n0; n < N; n += pl.cw) {
+        double acc = 0.0;
+        for (int b0 = r; b0 < count; b0 += kBatch * pl.rg) {
+            double v[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int b = b0 + u * pl.rg;  // wave-uniform
+                v[u] = 0.0;
+                if (b < count) v[u] = src[(size_t)b * N + n];
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u)
+                if (b0 + u * pl.rg < count) acc += v[u];
+        }
+        s_red[r * N + n] = acc;
+    }
+}
+
+// row groups row_sums_to_lds uses, and the doubles of LDS it needs
+__host__ __device__ inline int row_sum_groups(int N, int T)
+{
+    int cw = (((N & 1) == 0 ? N >> 1 : N) + 63) & ~63;
+    if (cw > T) cw = T;
+    return T / cw;
+}
+
+__host__ __device__ inline size_t row_sum_lds_doubles(int N, int T) { return (size_t)row_sum_groups(N, T) * N; }
+
+// second half: the rg partial sums of column n, added in group order
+__device__ __forceinline__ double row_sums_total(const double *s_red, int N, int n, int rg)
+{
+    double total = 0.0;
+    for (int r = 0; r < rg; ++r) total += s_red[r * N + n];
+    return total;
+}
+
+// ---- scalar helpers -----------------------------------------------------------------
+
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+
+__device__ __forceinline__ double fast_rsq(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-x * y, y, 1.0);
+    return fma(0.5 * y, e, y);
+}
+
+// L/:388-389: lj = (1/(sq nv)) (1 - 1/sqrt(1 + ratio nv)), with the reciprocal and the
+// reciprocal square root from the hardware estimate plus two Newton steps (full fp64
+// precision at a fraction of the latency of the IEEE divide and sqrt sequences)
+__device__ __forceinline__ double lj_of(double nv, double sq, double ratio)
+{
+    return fast_rcp(sq * nv) * (1 - fast_rsq(1 + ratio * nv));
+}
+
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const int o = __shfl_xor(v, s, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+#ifdef LMCMA_DIAG
+// diagnostic build only: wall-clock stamps (100 MHz counter) of kernel phases
+static __device__ unsigned long long g_update_stamps[16];
+#define LMCMA_STAMP(i)                                                                    \
+    do {                                                                                  \
+        if (threadIdx.x == 0) g_update_stamps[i] = __builtin_amdgcn_s_memrealtime();      \
+    } while (0)
+#else
+#define LMCMA_STAMP(i)
+#endif
+
+// LDS doubles the update needs for (N, m) with T threads
+__host__ __device__ inline size_t update_lds_doubles(int N, int m, int T, bool v_lds)
+{
+    return (v_lds ? (size_t)m * N : 0) + (size_t)N + row_sum_lds_doubles(N, T) + 2 * LMCMA_HIP_MAX_VECTORS;
+}
+
+// One workgroup of T >= 16 m threads (T a multiple of 64, at most 1024).  The 16 lanes
+// of group g own SLOT g of the direction store (EMAX >= N / 16 coordinates per lane in
+// registers), so every load of the kernel can be issued at its start: nothing waits for
+// the slot tables.  V_LDS: finished vectors are published through LDS (m * N doubles,
+// by position in the time-ordered list), otherwise through their home rows in global
+// memory.  Global stores are kept out of the loop (a workgroup barrier waits for
+// outstanding stores) and issued at the end.
+template <int EMAX, bool V_LDS>
+__device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn)
+{
+    constexpr bool KEEP_PC = EMAX <= 8;  // evolution paths stay in registers when they fit
+    const int T = blockDim.x;
+    const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
+    const int N = a.N, m = a.m, lambda = a.lambda;
+    OptScalars &o = *a.opt;
+    const double sigma = o.sigma, cc = o.cc, c1 = o.c1, K = o.K, Mfac = o.M;
+    const int itr = o.itr;
+
+    double *s_v = s_dyn;                                  // [m][N] when V_LDS, by position
+    double *s_pc = s_dyn + (V_LDS ? (size_t)m * N : 0);   // [N] new evolution path
+    double *s_red = s_pc + N;                             // [rg][N] partial column sums
+    double *s_nv = s_red + row_sum_lds_doubles(N, T);               // [64], |v_i|^2 by position i
+    double *s_ljp = s_nv + LMCMA_HIP_MAX_VECTORS;         // [64], lj of the untouched vectors by position
+
+    LMCMA_STAMP(0);
+    // ---- every load of the kernel
+    // slot tables, one entry per lane, the same copy in every wave (m <= 64): position j
+    // of the time-ordered list is slot t[j]; slot s was written in generation vec[s]
+    int t_reg = 0, vec_reg = 0;
+    if (wl < m) {
+        t_reg = a.t[wl];
+        vec_reg = a.vec[wl];
+    }
+    const bool has_slot = grp < m;
+    const int slot = has_slot ? grp : 0;
+    const double lj_old = a.lj[slot], nj_old = a.nj[slot];
+    // old mean and evolution path of this thread's columns (N <= 512, T >= 256: at most two)
+    double xold[2] = {0.0, 0.0}, pcold[2] = {0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int n = tid + q * T;
+        if (n < N) {
+            xold[q] = a.xmean[n];
+            pcold[q] = a.pc[n];
+        }
+    }
+    // success-rule count (the sum over this generation's candidates of the number of last
+    // generation's costs below it): wave 0 reads the per-workgroup shares, up to 1024 of them
+    uint32_t pp[16];
+    unsigned long long psr_lane = 0ull;
+    float best_in = 0.f;
+    if (tid < 64) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            pp[u] = 0u;
+            if (64 * u < a.n_psr_parts) {  // uniform
+                const int b = tid + 64 * u;
+                pp[u] = a.psr_parts[b < a.n_psr_parts ? b : a.n_psr_parts - 1];
+                if (b >= a.n_psr_parts) pp[u] = 0u;
+            }
+        }
+        if (tid == 0) {
+            psr_lane = *a.psr_accum;
+            best_in = a.sorted_cost[0];  // this generation's lowest cost
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) pp[u] = 0u;
+    }
+    double vold[EMAX], pcq[EMAX];
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        const int n = e * 16 + lane;
+        const size_t at = (size_t)slot * N + (n < N ? n : N - 1);
+        pcq[e] = a.pc_arr[at];
+        vold[e] = a.v_arr[at];
+    }
+    // L/:316-329: the rank-ordered partial sums of the new mean
+    row_sums_to_lds(a.partials, a.n_partials, N, s_red);
+    LMCMA_STAMP(1);
+
+    // ---- L/:331-364: which slot receives the new direction.  Every wave works it out for
+    // itself in registers.
+    int imin = 1;
+    if (itr < m) {
+        if (wl == itr) t_reg = itr;
+    } else if (m > 1) {
+        const int vt = __shfl(vec_reg, t_reg, 64);  // vec[t[j]] in lane j
+        const int vnext = __shfl_down(vt, 1, 64);
+        const int gap = (wl < m - 1) ? vnext - vt : 0x7fffffff;
+        const int dmin = wave_min_i32(gap);
+        // first position with the smallest gap (the reference replaces on strict "<" only)
+        imin = __ffsll((unsigned long long)__ballot(gap == dmin));
+        if (dmin >= m) imin = 0;  // maxsteps = nvectors (L/:267)
+        if (imin != m - 1) {
+            const int sav = __shfl(t_reg, imin, 64);
+            const int nxt = __shfl_down(t_reg, 1, 64);
+            if (wl >= imin && wl < m - 1) t_reg = nxt;
+            if (wl == m - 1) t_reg = sav;
+        }
+    } else {
+        imin = 0;
+    }
+    const int isz = itr + 1 < m ? itr + 1 : m;
+    const int newidx = __shfl(t_reg, isz - 1, 64);
+    if (wl == newidx) vec_reg = itr;
+    if (imin == 1) imin = 0;  // L/:373-374
+
+    // position of this group's slot in the time-ordered list (-1: the slot is not in use)
+    int pos = -1;
+    {
+        const int g0 = (tid >> 6) << 2;  // first group of this wave
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned long long hit = __ballot(wl < isz && t_reg == g0 + q);
+            if ((grp & 3) == q && hit != 0ull) pos = __ffsll(hit) - 1;
+        }
+    }
+    const bool own = has_slot && pos >= 0;
+    const bool rebuild = own && pos >= imin;
+    const bool newest = own && slot == newidx;  // L/:365-366: takes the new evolution path
+
+    // success-rule count: wave 0 adds its lanes' shares
+#pragma unroll
+    for (int u = 0; u < 16; ++u) psr_lane += pp[u];
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) psr_lane += __shfl_xor(psr_lane, sft, 64);
+
+    const double pc_gain = sqrt(cc * (2 - cc) * o.mueff);
+    const double sq = sqrt(1 - c1), ratio = c1 / (1 - c1);
+
+    // L/:393-419: population success rule, by thread 0.  In the merged stable sort of
+    // [current | previous] an element of the current generation at sorted position i gets
+    // rank i + #{previous < it}; psr_lane is the sum of the second term.  The reference's
+    // "meanprev" is the mean rank of the current generation and "meancur" that of the
+    // previous one.
+    double new_sigma = sigma, new_s = 0.0, new_best = 0.0, mk = 1.0;
+    long long new_counteval = 0;
+    if (tid == 0) {
+        new_s = o.s;
+        if (itr > 0) {
+            const long long cur_sum = (long long)lambda * (lambda - 1) / 2 + (long long)psr_lane;
+            const long long total = (long long)lambda * (2ll * lambda - 1);  // sum of 0..2*lambda-1
+            const double mean_current = (double)cur_sum / lambda;
+            const double mean_previous = (double)(total - cur_sum) / lambda;
+            const double diffv = (mean_previous - mean_current) / lambda;
+            const double z1 = diffv - o.val_target;
+            new_s = (1 - o.cs) * new_s + o.cs * z1;
+            new_sigma = sigma * exp(new_s / 1.0);
+        }
+        // CMABase::setEvaluationFeedback bookkeeping, L/:191-198, for lambda candidates
+        const double best = (double)best_in;
+        new_counteval = o.counteval;
+        new_best = (best < o.best_f || new_counteval == 0) ? best : o.best_f;
+        new_counteval += lambda;
+        for (int q = 0; q < isz; ++q) mk *= Mfac;  // M^k of the next sampling pass
+    }
+
+    // vectors that are not rebuilt are final already: publish them and their norms
+    double av[EMAX];
+    double aa = 0.0;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        const int n = e * 16 + lane;
+        const bool in = own && n < N;
+        if (!in) pcq[e] = 0.0;
+        av[e] = in ? (rebuild ? pcq[e] : vold[e]) : 0.0;  // L/:376-377: a rebuilt vector starts from its path
+    }
+    if (!rebuild) {
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const int n = e * 16 + lane;
+            aa += av[e] * av[e];
+            if (V_LDS && own && n < N) s_v[(size_t)pos * N + n] = av[e];
+        }
+        aa = row16_sum(aa);
+        if (own && lane == 0) {
+            s_nv[pos] = aa;
+            s_ljp[pos] = lj_old;
+        }
+    }
+    __syncthreads();
+    LMCMA_STAMP(2);
+    // L/:316-329: new mean, evolution path
+    double xnew[2] = {0.0, 0.0}, pcn[2] = {0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int n = tid + q * T;
+        if (n < N) {
+            xnew[q] = row_sums_total(s_red, N, n, row_sum_groups(N, T));
+            pcn[q] = (1 - cc) * pcold[q] + pc_gain * (xnew[q] - xold[q]) / sigma;
+            s_pc[n] = pcn[q];
+        }
+    }
+    __syncthreads();
+    LMCMA_STAMP(3);
+
+    // L/:375-390 with invAz (:449-463).  Vector i is v_i = T_{i-1} ... T_0 pc_i with
+    // T_j = K I - lj_j v_j v_j^T.  The reference finishes vector i before it starts
+    // i+1; here j is the outer loop and every unfinished vector applies T_j at the same
+    // time (one 16-lane group per vector, the vector in registers), so each vector
+    // still sees exactly the reference's sequence of operations.  Vectors before imin
+    // keep last generation's value (L/:375 starts at imin).
+    //
+    // The squared norm of every vector is carried along instead of being summed again
+    // after the last transform: |K a - d v|^2 = K^2 |a|^2 - 2 K d (v.a) + d^2 |v|^2, all of
+    // whose terms are already in registers; so a step needs one cross-lane sum only.
+    if (rebuild) {
+        aa = 0.0;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const int n = e * 16 + lane;
+            if (newest) {
+                av[e] = n < N ? s_pc[n] : 0.0;
+                pcq[e] = av[e];
+            }
+            aa += av[e] * av[e];
+        }
+        aa = row16_sum(aa);
+    }
+    if (!KEEP_PC) {
+        // the paths are read again at the end; keep the registers for the loop
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) pcq[e] = 0.0;
+    }
+    for (int i = 0; i < isz; ++i) {
+        const bool fresh = i >= imin;  // same for every thread
+        const int slot_i = __shfl(t_reg, i, 64);
+        if (fresh) {
+            // vector i has received T_0..T_{i-1}: it is final, its owner publishes it and its
+            // squared norm; vectors before imin were published above, once
+            if (pos == i) {
+                double *dst = V_LDS ? s_v + (size_t)i * N : a.v_arr + (size_t)slot * N;
+#pragma unroll
+                for (int e = 0; e < EMAX; ++e) {
+                    const int n = e * 16 + lane;
+                    if (n < N) dst[n] = av[e];
+                }
+                if (lane == 0) s_nv[i] = aa;
+            }
+            // The next publication writes row i+1 and another norm word, so one barrier per
+            // step is enough.
+            __syncthreads();
+        }
+        // T_i on every later vector that is being rebuilt
+        if (rebuild && pos > i) {
+            const double *vi = V_LDS ? s_v + (size_t)i * N : a.v_arr + (size_t)slot_i * N;
+            double vv[EMAX];
+            double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+            for (int e = 0; e < EMAX; e += 2) {
+                const int n0 = e * 16 + lane, n1 = (e + 1) * 16 + lane;
+                vv[e] = n0 < N ? vi[n0] : 0.0;
+                vv[e + 1] = n1 < N ? vi[n1] : 0.0;
+                p0 += vv[e] * av[e];
+                p1 += vv[e + 1] * av[e + 1];
+            }
+            const double nvi = s_nv[i];
+            // every group derives lj_i from the published norm itself (arithmetic that hides
+            // behind the LDS reads above) instead of waiting for the owner to do it
+            const double lji = fresh ? lj_of(nvi, sq, ratio) : s_ljp[i];
+            const double p = row16_sum(p0 + p1);
+            const double d = lji * p;
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) av[e] = K * av[e] - d * vv[e];
+            aa = K * K * aa - 2.0 * K * d * p + d * d * nvi;
+        }
+    }
+    LMCMA_STAMP(4);
+
+    // L/:386-389 for the rebuilt vectors (all 16 lanes of a group hold the same norm)
+    double nj_new = nj_old;
+    if (rebuild) nj_new = (sq / aa) * (sqrt(1 + ratio * aa) - 1);
+
+    // state back to memory, and the float images the sampling kernel reads, by position q:
+    // V_f[q] = v_q, B_f[q] = M^(k-1-q) nj_q pc_q
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int n = tid + q * T;
+        if (n < N) {
+            a.xmean[n] = xnew[q];
+            a.pc[n] = pcn[q];
+        }
+        if (n < a.ld) a.xmean_f[n] = (n < N) ? (float)xnew[q] : 0.f;
+    }
+    if (tid < m) {
+        a.t[tid] = t_reg;
+        a.vec[tid] = vec_reg;
+        if (tid < isz) a.iterator[tid] = t_reg;
+    }
+    if (own) {
+        if (rebuild && lane == 0) {
+            a.nj[slot] = nj_new;
+            a.lj[slot] = lj_of(aa, sq, ratio);
+        }
+        double coef = nj_new;
+        for (int e = 0; e < isz - 1 - pos; ++e) coef *= Mfac;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const int n = e * 16 + lane;
+            double pv = pcq[e];
+            if (!KEEP_PC) pv = n < N ? (newest ? s_pc[n] : a.pc_arr[(size_t)slot * N + n]) : 0.0;
+            if (n < N) {
+                if (newest) a.pc_arr[(size_t)slot * N + n] = pv;
+                if (rebuild && V_LDS) a.v_arr[(size_t)slot * N + n] = av[e];
+            }
+            if (n < a.ld) {
+                a.V_f[(size_t)pos * a.ld + n] = (n < N) ? (float)av[e] : 0.f;
+                a.B_f[(size_t)pos * a.ld + n] = (n < N) ? (float)(coef * pv) : 0.f;
+            }
+        }
+    }
+    if (tid == 0) {
+        o.s = new_s;
+        o.sigma = new_sigma;
+        o.best_f = new_best;
+        o.counteval = new_counteval;
+        o.itr = itr + 1;
+        o.iterator_sz = isz;
+        o.imin_last = imin;
+        a.sc->sigma = (float)new_sigma;
+        a.sc->mk = (float)mk;
+        a.sc->k = isz;
+        a.sc->generation = (uint32_t)(itr + 1);
+        *a.psr_accum = 0ull;  // ready for the next generation's ranking
+    }
+    LMCMA_STAMP(5);
+}
+
+}  // namespace lmcma
