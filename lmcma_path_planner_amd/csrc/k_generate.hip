@@ -35,19 +35,52 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
     const float mk = g.sc->mk;
     const uint32_t generation = g.sc->generation;
 
+    constexpr int LDP = J * 128;               // LDS stride of a direction vector: reads need no bounds
     float *srows = smem;                       // [kTile][ld]
-    float *sV = srows + kTile * ld;            // [m][ld] when VB_LDS
-    float *sB = sV + (VB_LDS ? g.m * ld : 0);  // [m][ld] when VB_LDS
-    uint32_t *sbits = reinterpret_cast<uint32_t *>(sB + (VB_LDS ? g.m * ld : 0));
+    float *sV = srows + kTile * ld;            // [m][LDP] when VB_LDS, zero beyond ld
+    float *sB = sV + (VB_LDS ? g.m * LDP : 0); // [m][LDP] when VB_LDS, zero beyond ld
+    uint32_t *sbits = reinterpret_cast<uint32_t *>(sB + (VB_LDS ? g.m * LDP : 0));
 
+    const int lane = threadIdx.x & (kLanes - 1);
+    const int slot = threadIdx.x / kLanes;
+    // The update kernel wrote the mean and V, B, so their first touch misses this XCD's
+    // L2: every such load of the kernel is requested here, before anything waits.
+    // mean and bounds of this lane's chunks (used after the sampling loop)
+    float4 xm[J], l4[J], h4[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int chunk = j * kLanes + lane;
+        const int cc = chunk < nchunks ? chunk : nchunks - 1;
+        xm[j] = reinterpret_cast<const float4 *>(g.xmean)[cc];
+        l4[j] = reinterpret_cast<const float4 *>(g.lo)[cc];
+        h4[j] = reinterpret_cast<const float4 *>(g.hi)[cc];
+    }
     if (VB_LDS) {
-        const int n4 = (k * ld) >> 2;
+        // All m rows, whatever k is: the copy then does not wait for the scalar load of k.
+        const int n4 = g.m * (LDP >> 2);
         const float4 *srcV = reinterpret_cast<const float4 *>(g.V);
         const float4 *srcB = reinterpret_cast<const float4 *>(g.B);
         float4 *dstV = reinterpret_cast<float4 *>(sV), *dstB = reinterpret_cast<float4 *>(sB);
-        for (int i = threadIdx.x; i < n4; i += 256) {
-            dstV[i] = srcV[i];
-            dstB[i] = srcB[i];
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * 256) {
+            float4 tv[4], tb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256;
+                const int row = i / (LDP >> 2), col = i % (LDP >> 2);
+                const int at = (row < g.m ? row : g.m - 1) * nchunks + (col < nchunks ? col : nchunks - 1);
+                tv[u] = srcV[at];
+                tb[u] = srcB[at];
+            }
+            asm volatile("" ::: "memory");  // the loads of a batch are all issued before the first LDS store
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256;
+                if (i < n4) {
+                    const bool pad = i % (LDP >> 2) >= nchunks;
+                    dstV[i] = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : tv[u];
+                    dstB[i] = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : tb[u];
+                }
+            }
         }
     }
     const uint32_t *bits;
@@ -62,8 +95,6 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
     const float *Vp = VB_LDS ? sV : g.V;
     const float *Bp = VB_LDS ? sB : g.B;
 
-    const int lane = threadIdx.x & (kLanes - 1);
-    const int slot = threadIdx.x / kLanes;
     const int ntiles = (g.n_local + kTile - 1) / kTile;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -93,11 +124,11 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
             for (int u = 0; u < U; ++u) {
                 d[u] = 0.f;
                 if (t0 + u < k) {
-                    const float4 *v = reinterpret_cast<const float4 *>(Vp + (size_t)(t0 + u) * ld);
+                    const float4 *v = reinterpret_cast<const float4 *>(Vp + (size_t)(t0 + u) * (VB_LDS ? LDP : ld));
 #pragma unroll
                     for (int j = 0; j < J; ++j) {
                         const int chunk = j * kLanes + lane;
-                        if (chunk < nchunks) {
+                        if (VB_LDS || chunk < nchunks) {
                             const float4 vv = v[chunk];
                             d[u] = fmaf(vv.x, z[j].x, d[u]);
                             d[u] = fmaf(vv.y, z[j].y, d[u]);
@@ -112,11 +143,11 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (t0 + u < k) {
-                    const float4 *b = reinterpret_cast<const float4 *>(Bp + (size_t)(t0 + u) * ld);
+                    const float4 *b = reinterpret_cast<const float4 *>(Bp + (size_t)(t0 + u) * (VB_LDS ? LDP : ld));
 #pragma unroll
                     for (int j = 0; j < J; ++j) {
                         const int chunk = j * kLanes + lane;
-                        if (chunk < nchunks) {
+                        if (VB_LDS || chunk < nchunks) {
                             const float4 bb = b[chunk];
                             acc[j].x = fmaf(d[u], bb.x, acc[j].x);
                             acc[j].y = fmaf(d[u], bb.y, acc[j].y);
@@ -134,15 +165,12 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
         for (int j = 0; j < J; ++j) {
             const int chunk = j * kLanes + lane;
             if (chunk < nchunks) {
-                const float4 xm = reinterpret_cast<const float4 *>(g.xmean)[chunk];
-                const float4 l4 = reinterpret_cast<const float4 *>(g.lo)[chunk];
-                const float4 h4 = reinterpret_cast<const float4 *>(g.hi)[chunk];
                 float4 x;
                 // max with the lower bound first, then min with the upper one (lmcma.cpp:222-229)
-                x.x = fminf(fmaxf(fmaf(sigma, acc[j].x, xm.x), l4.x), h4.x);
-                x.y = fminf(fmaxf(fmaf(sigma, acc[j].y, xm.y), l4.y), h4.y);
-                x.z = fminf(fmaxf(fmaf(sigma, acc[j].z, xm.z), l4.z), h4.z);
-                x.w = fminf(fmaxf(fmaf(sigma, acc[j].w, xm.w), l4.w), h4.w);
+                x.x = fminf(fmaxf(fmaf(sigma, acc[j].x, xm[j].x), l4[j].x), h4[j].x);
+                x.y = fminf(fmaxf(fmaf(sigma, acc[j].y, xm[j].y), l4[j].y), h4[j].y);
+                x.z = fminf(fmaxf(fmaf(sigma, acc[j].z, xm[j].z), l4[j].z), h4[j].z);
+                x.w = fminf(fmaxf(fmaf(sigma, acc[j].w, xm[j].w), l4[j].w), h4[j].w);
                 lrow[chunk] = x;
                 if (live) out[chunk] = x;
             }
@@ -185,7 +213,7 @@ hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds)
 {
     const int ntiles = (g.n_local + kTile - 1) / kTile;
     const size_t rows_b = (size_t)kTile * g.ld * sizeof(float);
-    const size_t vb_b = 2 * (size_t)g.m * g.ld * sizeof(float);
+    const size_t vb_b = 2 * (size_t)g.m * (J * 128) * sizeof(float);  // rows padded to the lanes' reach
     const size_t grid_b = grid_lds ? (size_t)g.cost.grid_words * sizeof(uint32_t) : 0;
     const size_t budget = 160 * 1024;
     const bool vb_lds = rows_b + vb_b + grid_b <= budget && g.m <= 32;

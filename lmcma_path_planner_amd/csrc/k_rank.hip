@@ -343,7 +343,10 @@ bool select_by_counting(int lambda)
 // candidates per workgroup of the counting path: 16 lanes each
 int select_candidates_per_block(int lambda)
 {
-    int threads = 256;
+    // 512 threads = 32 candidates per workgroup: measured best at lambda = 4096 (a smaller
+    // workgroup counts faster but leaves twice as many partial rows for the one-workgroup
+    // update to read, a larger one the other way round)
+    int threads = lambda >= 1024 ? 512 : 256;
     if (const char *f = getenv("LMCMA_HIP_RANK_THREADS")) {
         const int v = atoi(f);
         if (v == 256 || v == 512 || v == 1024) threads = v;

@@ -56,18 +56,20 @@ __global__ __launch_bounds__(1024) void k_recombine_final(const double *__restri
                                                           double *__restrict__ partial_local)
 {
     __shared__ double s_red[2048];  // row_sum_lds_doubles(N <= 512, T <= 1024)
-    row_sums_to_lds(block_partials, nblocks, N, s_red);
+    row_sums_to_lds(block_partials, nblocks, N, (int)blockDim.x, s_red);
     __syncthreads();
     for (int n = threadIdx.x; n < N; n += blockDim.x) partial_local[n] = row_sums_total(s_red, N, n, row_sum_groups(N, (int)blockDim.x));
 }
 
 // ---- update, stand-alone ------------------------------------------------------------
+// TB threads do the vector work; the launch adds one wave for the step-size rule when the
+// workgroup has room for it
 template <int TB, int EMAX, bool V_LDS>
-__global__ __launch_bounds__(TB) void k_update(const UpdateArgs a)
+__global__ __launch_bounds__(TB < 1024 ? TB + 64 : 1024) void k_update(const UpdateArgs a)
 {
     // all LDS in one dynamic array of doubles
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-    update_body<EMAX, V_LDS>(a, s_dyn);
+    update_body<EMAX, V_LDS>(a, s_dyn, TB);
 }
 
 }  // namespace
@@ -130,7 +132,7 @@ static hipError_t launch_update_t(hipStream_t s, const UpdateArgs &a)
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL((k_update<TB, EMAX, V_LDS>), dim3(1), dim3(TB), lds, s, a);
+    hipLaunchKernelGGL((k_update<TB, EMAX, V_LDS>), dim3(1), dim3(TB < 1024 ? TB + 64 : 1024), lds, s, a);
     return hipGetLastError();
 }
 

@@ -39,11 +39,38 @@ __device__ __forceinline__ RowSumPlan row_sum_plan2(int N, int T)
 // L2, and one workgroup has to keep many wide loads in flight to read them at any speed:
 // 16 bytes per lane (even N; a single workgroup reads such data about twice as fast with
 // 16-byte as with 8-byte loads) and up to 16 loads per thread at once.
-__device__ __forceinline__ void row_sums_to_lds(const double *src, int count, int N, double *s_red)
+constexpr int kRowBatch = 16;
+
+// The first batch of loads of row_sums_to_lds (even N), issued early: a caller with other
+// work to do between the request and the use calls row_sums_begin, does that work, then
+// row_sums_to_lds with the same arguments and the batch.
+struct RowSumBatch {
+    double2 v[kRowBatch];
+};
+
+__device__ __forceinline__ void row_sums_begin(const double *src, int count, int N, int T, RowSumBatch &first)
 {
-    constexpr int kBatch = 16;
+#pragma unroll
+    for (int u = 0; u < kRowBatch; ++u) first.v[u] = make_double2(0.0, 0.0);
+    if ((N & 1) != 0) return;
+    const RowSumPlan pl = row_sum_plan2(N, T);
+    const int r = __builtin_amdgcn_readfirstlane((int)threadIdx.x / pl.cw);
+    const int n = 2 * ((int)threadIdx.x % pl.cw);
+    if (r >= pl.rg || n >= N) return;
+#pragma unroll
+    for (int u = 0; u < kRowBatch; ++u) {
+        const int b = r + u * pl.rg;  // wave-uniform
+        if (b < count) first.v[u] = *reinterpret_cast<const double2 *>(src + (size_t)b * N + n);
+    }
+}
+
+template <bool HAVE_FIRST>
+__device__ __forceinline__ void row_sums_to_lds_t(const double *src, int count, int N, int T, double *s_red,
+                                                  const RowSumBatch &first)
+{
+    constexpr int kBatch = kRowBatch;
     if ((N & 1) == 0) {
-        const RowSumPlan pl = row_sum_plan2(N, (int)blockDim.x);
+        const RowSumPlan pl = row_sum_plan2(N, T);
         // cw is a multiple of 64 (or the whole workgroup), so r is the same in every lane of a wave
         const int r = __builtin_amdgcn_readfirstlane((int)threadIdx.x / pl.cw);
         const int n0 = 2 * ((int)threadIdx.x % pl.cw);
@@ -52,13 +79,18 @@ __device__ __forceinline__ void row_sums_to_lds(const double *src, int count, in
             double a0 = 0.0, a1 = 0.0;
             for (int b0 = r; b0 < count; b0 += kBatch * pl.rg) {
                 double2 v[kBatch];
+                if (HAVE_FIRST && n == n0 && b0 == r) {
 #pragma unroll
-                for (int u = 0; u < kBatch; ++u) {
-                    const int b = b0 + u * pl.rg;  // wave-uniform
-                    v[u] = make_double2(0.0, 0.0);
-                    if (b < count) v[u] = *reinterpret_cast<const double2 *>(src + (size_t)b * N + n);
+                    for (int u = 0; u < kBatch; ++u) v[u] = first.v[u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) {
+                        const int b = b0 + u * pl.rg;  // wave-uniform
+                        v[u] = make_double2(0.0, 0.0);
+                        if (b < count) v[u] = *reinterpret_cast<const double2 *>(src + (size_t)b * N + n);
+                    }
+                    asm volatile("" ::: "memory");  // all loads of the batch are issued before the first add
                 }
-                asm volatile("" ::: "memory");  // all loads of the batch are issued before the first add
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u)
                     if (b0 + u * pl.rg < count) {
@@ -71,7 +103,7 @@ __device__ __forceinline__ void row_sums_to_lds(const double *src, int count, in
         }
         return;
     }
-    const RowSumPlan pl = row_sum_plan(N, (int)blockDim.x);
+    const RowSumPlan pl = row_sum_plan(N, T);
     const int r = __builtin_amdgcn_readfirstlane((int)threadIdx.x / pl.cw);
     const int n0 = (int)threadIdx.x % pl.cw;
     if (r >= pl.rg) return;
@@ -92,6 +124,12 @@ __device__ __forceinline__ void row_sums_to_lds(const double *src, int count, in
         }
         s_red[r * N + n] = acc;
     }
+}
+
+__device__ __forceinline__ void row_sums_to_lds(const double *src, int count, int N, int T, double *s_red)
+{
+    RowSumBatch none;
+    row_sums_to_lds_t<false>(src, count, N, T, s_red, none);
 }
 
 // row groups row_sums_to_lds uses, and the doubles of LDS it needs
@@ -164,10 +202,13 @@ static __device__ unsigned long long g_update_stamps[16];
 // LDS doubles the update needs for (N, m) with T threads
 __host__ __device__ inline size_t update_lds_doubles(int N, int m, int T, bool v_lds)
 {
-    return (v_lds ? (size_t)m * N : 0) + (size_t)N + row_sum_lds_doubles(N, T) + 2 * LMCMA_HIP_MAX_VECTORS;
+    const size_t np = N <= 128 ? 128 : N <= 256 ? 256 : 512;  // 16 lanes x 8, 16 or 32 coordinates
+    return (v_lds ? (size_t)m * np : 0) + np + row_sum_lds_doubles(N, T) + 2 * LMCMA_HIP_MAX_VECTORS;
 }
 
-// One workgroup of T >= 16 m threads (T a multiple of 64, at most 1024).  The 16 lanes
+// T >= 16 m threads (T a multiple of 64) of one workgroup do the vector work; when the
+// workgroup has one more wave, that wave evaluates the step-size rule beside them (its
+// divisions and exponential would otherwise hold up a wave the others wait for).  The 16 lanes
 // of group g own SLOT g of the direction store (EMAX >= N / 16 coordinates per lane in
 // registers), so every load of the kernel can be issued at its start: nothing waits for
 // the slot tables.  V_LDS: finished vectors are published through LDS (m * N doubles,
@@ -175,19 +216,26 @@ __host__ __device__ inline size_t update_lds_doubles(int N, int m, int T, bool v
 // memory.  Global stores are kept out of the loop (a workgroup barrier waits for
 // outstanding stores) and issued at the end.
 template <int EMAX, bool V_LDS>
-__device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn)
+__device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, int T)
 {
     constexpr bool KEEP_PC = EMAX <= 8;  // evolution paths stay in registers when they fit
-    const int T = blockDim.x;
     const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
     const int N = a.N, m = a.m, lambda = a.lambda;
     OptScalars &o = *a.opt;
     const double sigma = o.sigma, cc = o.cc, c1 = o.c1, K = o.K, Mfac = o.M;
     const int itr = o.itr;
+    const bool worker = tid < T;
+    const int stid = (int)blockDim.x > T ? T : 0;  // the thread that evaluates the step-size rule
+    const bool swave = (tid >> 6) == (stid >> 6);
+    // read now, used by one thread in the step-size rule: a load issued there would have to
+    // wait for every load requested before it
+    const double o_mueff = o.mueff, o_s = o.s, o_cs = o.cs, o_val_target = o.val_target, o_best_f = o.best_f;
+    const long long o_counteval = o.counteval;
 
-    double *s_v = s_dyn;                                  // [m][N] when V_LDS, by position
-    double *s_pc = s_dyn + (V_LDS ? (size_t)m * N : 0);   // [N] new evolution path
-    double *s_red = s_pc + N;                             // [rg][N] partial column sums
+    constexpr int NP = EMAX * 16;                          // row stride in LDS: reads and writes need no bounds
+    double *s_v = s_dyn;                                  // [m][NP] when V_LDS, by position; zero beyond N
+    double *s_pc = s_dyn + (V_LDS ? (size_t)m * NP : 0);  // [NP] new evolution path, zero beyond N
+    double *s_red = s_pc + NP;                            // [rg][N] partial column sums
     double *s_nv = s_red + row_sum_lds_doubles(N, T);               // [64], |v_i|^2 by position i
     double *s_ljp = s_nv + LMCMA_HIP_MAX_VECTORS;         // [64], lj of the untouched vectors by position
 
@@ -208,27 +256,25 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int n = tid + q * T;
-        if (n < N) {
+        if (worker && n < N) {
             xold[q] = a.xmean[n];
             pcold[q] = a.pc[n];
         }
     }
     // success-rule count (the sum over this generation's candidates of the number of last
-    // generation's costs below it): wave 0 reads the per-workgroup shares, up to 1024 of them
+    // generation's costs below it): one wave reads the per-workgroup shares, up to 1024 of them
     uint32_t pp[16];
     unsigned long long psr_lane = 0ull;
     float best_in = 0.f;
-    if (tid < 64) {
+    if (swave) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            pp[u] = 0u;
-            if (64 * u < a.n_psr_parts) {  // uniform
-                const int b = tid + 64 * u;
-                pp[u] = a.psr_parts[b < a.n_psr_parts ? b : a.n_psr_parts - 1];
-                if (b >= a.n_psr_parts) pp[u] = 0u;
-            }
+            // no branch around the load (entries past the end re-read word 0 and are dropped
+            // below): sixteen independent requests, none waits for another
+            const int b = wl + 64 * u;
+            pp[u] = a.psr_parts[b < a.n_psr_parts ? b : 0];
         }
-        if (tid == 0) {
+        if (tid == stid) {
             psr_lane = *a.psr_accum;
             best_in = a.sorted_cost[0];  // this generation's lowest cost
         }
@@ -244,8 +290,11 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn)
         pcq[e] = a.pc_arr[at];
         vold[e] = a.v_arr[at];
     }
-    // L/:316-329: the rank-ordered partial sums of the new mean
-    row_sums_to_lds(a.partials, a.n_partials, N, s_red);
+    // L/:316-329: the rank-ordered partial sums of the new mean; the slot bookkeeping and the
+    // step-size rule below run while these loads are in flight
+    RowSumBatch first_rows;
+    row_sums_begin(a.partials, a.n_partials, N, T, first_rows);
+    asm volatile("" ::: "memory");  // no load above is moved below this point
     LMCMA_STAMP(1);
 
     // ---- L/:331-364: which slot receives the new direction.  Every wave works it out for
@@ -291,36 +340,36 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn)
 
     // success-rule count: wave 0 adds its lanes' shares
 #pragma unroll
-    for (int u = 0; u < 16; ++u) psr_lane += pp[u];
+    for (int u = 0; u < 16; ++u) psr_lane += (wl + 64 * u < a.n_psr_parts) ? pp[u] : 0u;
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) psr_lane += __shfl_xor(psr_lane, sft, 64);
 
-    const double pc_gain = sqrt(cc * (2 - cc) * o.mueff);
+    const double pc_gain = sqrt(cc * (2 - cc) * o_mueff);
     const double sq = sqrt(1 - c1), ratio = c1 / (1 - c1);
 
-    // L/:393-419: population success rule, by thread 0.  In the merged stable sort of
+    // L/:393-419: population success rule, by one thread.  In the merged stable sort of
     // [current | previous] an element of the current generation at sorted position i gets
     // rank i + #{previous < it}; psr_lane is the sum of the second term.  The reference's
     // "meanprev" is the mean rank of the current generation and "meancur" that of the
     // previous one.
     double new_sigma = sigma, new_s = 0.0, new_best = 0.0, mk = 1.0;
     long long new_counteval = 0;
-    if (tid == 0) {
-        new_s = o.s;
+    if (tid == stid) {
+        new_s = o_s;
         if (itr > 0) {
             const long long cur_sum = (long long)lambda * (lambda - 1) / 2 + (long long)psr_lane;
             const long long total = (long long)lambda * (2ll * lambda - 1);  // sum of 0..2*lambda-1
             const double mean_current = (double)cur_sum / lambda;
             const double mean_previous = (double)(total - cur_sum) / lambda;
             const double diffv = (mean_previous - mean_current) / lambda;
-            const double z1 = diffv - o.val_target;
-            new_s = (1 - o.cs) * new_s + o.cs * z1;
+            const double z1 = diffv - o_val_target;
+            new_s = (1 - o_cs) * new_s + o_cs * z1;
             new_sigma = sigma * exp(new_s / 1.0);
         }
         // CMABase::setEvaluationFeedback bookkeeping, L/:191-198, for lambda candidates
         const double best = (double)best_in;
-        new_counteval = o.counteval;
-        new_best = (best < o.best_f || new_counteval == 0) ? best : o.best_f;
+        new_counteval = o_counteval;
+        new_best = (best < o_best_f || new_counteval == 0) ? best : o_best_f;
         new_counteval += lambda;
         for (int q = 0; q < isz; ++q) mk *= Mfac;  // M^k of the next sampling pass
     }
@@ -340,7 +389,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn)
         for (int e = 0; e < EMAX; ++e) {
             const int n = e * 16 + lane;
             aa += av[e] * av[e];
-            if (V_LDS && own && n < N) s_v[(size_t)pos * N + n] = av[e];
+            if (V_LDS && own) s_v[(size_t)pos * NP + n] = av[e];
         }
         aa = row16_sum(aa);
         if (own && lane == 0) {
@@ -348,6 +397,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn)
             s_ljp[pos] = lj_old;
         }
     }
+    row_sums_to_lds_t<true>(a.partials, a.n_partials, N, T, s_red, first_rows);
     __syncthreads();
     LMCMA_STAMP(2);
     // L/:316-329: new mean, evolution path
@@ -355,12 +405,13 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int n = tid + q * T;
-        if (n < N) {
+        if (worker && n < N) {
             xnew[q] = row_sums_total(s_red, N, n, row_sum_groups(N, T));
             pcn[q] = (1 - cc) * pcold[q] + pc_gain * (xnew[q] - xold[q]) / sigma;
             s_pc[n] = pcn[q];
         }
     }
+    for (int n = N + tid; n < NP; n += (int)blockDim.x) s_pc[n] = 0.0;
     __syncthreads();
     LMCMA_STAMP(3);
 
@@ -380,7 +431,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn)
         for (int e = 0; e < EMAX; ++e) {
             const int n = e * 16 + lane;
             if (newest) {
-                av[e] = n < N ? s_pc[n] : 0.0;
+                av[e] = s_pc[n];
                 pcq[e] = av[e];
             }
             aa += av[e] * av[e];
@@ -399,11 +450,11 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn)
             // vector i has received T_0..T_{i-1}: it is final, its owner publishes it and its
             // squared norm; vectors before imin were published above, once
             if (pos == i) {
-                double *dst = V_LDS ? s_v + (size_t)i * N : a.v_arr + (size_t)slot * N;
+                double *dst = V_LDS ? s_v + (size_t)i * NP : a.v_arr + (size_t)slot * N;
 #pragma unroll
                 for (int e = 0; e < EMAX; ++e) {
                     const int n = e * 16 + lane;
-                    if (n < N) dst[n] = av[e];
+                    if (V_LDS || n < N) dst[n] = av[e];
                 }
                 if (lane == 0) s_nv[i] = aa;
             }
@@ -413,14 +464,14 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn)
         }
         // T_i on every later vector that is being rebuilt
         if (rebuild && pos > i) {
-            const double *vi = V_LDS ? s_v + (size_t)i * N : a.v_arr + (size_t)slot_i * N;
+            const double *vi = V_LDS ? s_v + (size_t)i * NP : a.v_arr + (size_t)slot_i * N;
             double vv[EMAX];
             double p0 = 0.0, p1 = 0.0;
 #pragma unroll
             for (int e = 0; e < EMAX; e += 2) {
                 const int n0 = e * 16 + lane, n1 = (e + 1) * 16 + lane;
-                vv[e] = n0 < N ? vi[n0] : 0.0;
-                vv[e + 1] = n1 < N ? vi[n1] : 0.0;
+                vv[e] = (V_LDS || n0 < N) ? vi[n0] : 0.0;
+                vv[e + 1] = (V_LDS || n1 < N) ? vi[n1] : 0.0;
                 p0 += vv[e] * av[e];
                 p1 += vv[e + 1] * av[e + 1];
             }
@@ -446,11 +497,11 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int n = tid + q * T;
-        if (n < N) {
+        if (worker && n < N) {
             a.xmean[n] = xnew[q];
             a.pc[n] = pcn[q];
         }
-        if (n < a.ld) a.xmean_f[n] = (n < N) ? (float)xnew[q] : 0.f;
+        if (worker && n < a.ld) a.xmean_f[n] = (n < N) ? (float)xnew[q] : 0.f;
     }
     if (tid < m) {
         a.t[tid] = t_reg;
@@ -479,7 +530,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn)
             }
         }
     }
-    if (tid == 0) {
+    if (tid == stid) {
         o.s = new_s;
         o.sigma = new_sigma;
         o.best_f = new_best;

@@ -18,8 +18,8 @@ import shutil
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CLASS_OF = {"k_generate": "generate", "k_sample": "sample", "k_cost": "cost", "k_rank_count": "select",
-            "k_rank_finish": "select", "k_sort_tiles": "select", "k_merge_rank": "select", "k_psr_count": "select",
+CLASS_OF = {"k_generate": "generate", "k_sample": "sample", "k_cost": "cost", "k_rank": "select",
+            "k_sort_tiles": "select", "k_merge_rank": "select", "k_psr_count": "select",
             "k_recombine_partial": "recombine", "k_recombine_final": "recombine", "k_update": "update"}
 
 
