@@ -1003,12 +1003,14 @@ int lmcma_hip_synchronize(lmcma_hip_ctx *c)
 #ifdef LMCMA_DIAG
 hipError_t lmcma_diag_update_stamps(unsigned long long *out16);
 hipError_t lmcma_diag_rank_stamps(unsigned long long *out16);
-// which = 0: stamps of the stand-alone update kernel, 1: of the ranking kernel and its tail
+hipError_t lmcma_diag_generate_stamps(unsigned long long *out16);
+// which = 0: stamps of the update kernel, 1: of the ranking kernel, 2: of the generation kernel
 int lmcma_hip_diag_stamps(lmcma_hip_ctx *c, int which, unsigned long long *out16)
 {
     CTX_TRY(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(which ? lmcma_diag_rank_stamps(out16) : lmcma_diag_update_stamps(out16));
+    HIP_TRY(which == 2 ? lmcma_diag_generate_stamps(out16)
+                       : which ? lmcma_diag_rank_stamps(out16) : lmcma_diag_update_stamps(out16));
     return LMCMA_HIP_OK;
 }
 #endif

@@ -78,12 +78,43 @@ __device__ __forceinline__ T row16_sum(T v)
 }
 
 // sum over groups of G consecutive lanes (G = 16, 32 or 64), identical bits in every lane
+// The steps across rows use the gfx950 row-swap instructions (VALU, no LDS round trip):
+// v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its
+// second, so with both operands = v the two results are [r0 r0 r2 r2] and [r1 r1 r3 r3],
+// whose sum is what an exchange with lane ^ 16 would give; v_permlane32_swap does the same
+// with the two halves of the wave.
+__device__ __forceinline__ float add_lane_xor16(float v)
+{
+    const uint32_t b = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ float add_lane_xor32(float v)
+{
+    const uint32_t b = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ uint32_t add_lane_xor16(uint32_t v)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return r[0] + r[1];
+}
+
+__device__ __forceinline__ uint32_t add_lane_xor32(uint32_t v)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return r[0] + r[1];
+}
+
 template <int G>
 __device__ __forceinline__ float group_sum(float v)
 {
     v = row16_sum(v);
-    if (G >= 32) v += __shfl_xor(v, 16, 64);
-    if (G >= 64) v += __shfl_xor(v, 32, 64);
+    if (G >= 32) v = add_lane_xor16(v);
+    if (G >= 64) v = add_lane_xor32(v);
     return v;
 }
 
@@ -112,28 +143,44 @@ __device__ __forceinline__ float order_bits_inv(uint32_t k)
 
 // ---- trajectory cost ---------------------------------------------------------------
 
+// cell of the grid a point falls into
 template <int D>
-__device__ __forceinline__ float grid_value(const CostParams &p, const uint32_t *bits, const float *q)
+__device__ __forceinline__ int grid_cell(const CostParams &p, const float *q)
 {
     // clamp in float first: a NaN coordinate falls to cell 0, huge values saturate;
     // rintf rounds half to even like nearbyint
     const int ix = (int)rintf(fminf(fmaxf(q[0], 0.f), (float)(p.nx - 1)));
     const int iy = (D > 1) ? (int)rintf(fminf(fmaxf(q[1], 0.f), (float)(p.ny - 1))) : 0;
     const int iz = (D > 2) ? (int)rintf(fminf(fmaxf(q[2], 0.f), (float)(p.nz - 1))) : 0;
-    const int cell = (iz * p.ny + iy) * p.nx + ix;
+    return (iz * p.ny + iy) * p.nx + ix;
+}
+
+__device__ __forceinline__ float grid_value_at(const CostParams &p, const uint32_t *bits, int cell)
+{
     if (p.grid_type == LMCMA_GRID_BITS)
         return ((bits[cell >> 5] >> (cell & 31)) & 1u) ? p.c_obs : 0.f;
     return reinterpret_cast<const float *>(p.grid)[cell];
 }
 
-// Contribution of waypoint k of `row` (dimension-major, W per dimension) to the
-// three cost terms.  The trapezoid grid integral is regrouped per node:
-// 1/2 c(node) (len_prev + len_next), with the fixed endpoints' shares added at the
-// first and last waypoint.
 template <int D>
-__device__ __forceinline__ void waypoint_terms(const CostParams &p, const uint32_t *bits,
-                                               const float *row, int k, float &j_len, float &j_grid,
-                                               float &j_smooth)
+__device__ __forceinline__ float grid_value(const CostParams &p, const uint32_t *bits, const float *q)
+{
+    return grid_value_at(p, bits, grid_cell<D>(p, q));
+}
+
+// Contribution of waypoint k of `row` (dimension-major, W per dimension) to the
+// three cost terms, in two halves so that a caller can have the grid lookups of
+// several waypoints in flight at once: waypoint_prepare does everything up to the
+// cell index, waypoint_finish takes the grid value.  The trapezoid grid integral is
+// regrouped per node: 1/2 c(node) (len_prev + len_next), with the fixed endpoints'
+// shares added at the first and last waypoint.
+struct WaypointPart {
+    float len_prev, len_next, acc2;
+    int cell;
+};
+
+template <int D>
+__device__ __forceinline__ WaypointPart waypoint_prepare(const CostParams &p, const float *row, int k)
 {
     constexpr float c_far = -1.0f / 12.0f, c_near = 16.0f / 12.0f;
     const int W = p.W;
@@ -142,12 +189,16 @@ __device__ __forceinline__ void waypoint_terms(const CostParams &p, const uint32
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         const float *r = row + d * W;
+        // the neighbours are read at clamped indices and selected afterwards: five
+        // independent loads, no branch around any of them
         const float v0 = r[k];
-        const float vm1 = (k >= 1) ? r[k - 1] : p.start[d];
-        const float vp1 = (k + 1 < W) ? r[k + 1] : p.goal[d];
+        const float rm1 = r[k >= 1 ? k - 1 : 0], rp1 = r[k + 1 < W ? k + 1 : W - 1];
+        const float rm2 = r[k >= 2 ? k - 2 : 0], rp2 = r[k + 2 < W ? k + 2 : W - 1];
+        const float vm1 = (k >= 1) ? rm1 : p.start[d];
+        const float vp1 = (k + 1 < W) ? rp1 : p.goal[d];
         float sm1 = vm1, sp1 = vp1;
-        float sm2 = (k >= 2) ? r[k - 2] : p.start[d];
-        float sp2 = (k + 2 < W) ? r[k + 2] : p.goal[d];
+        float sm2 = (k >= 2) ? rm2 : p.start[d];
+        float sp2 = (k + 2 < W) ? rp2 : p.goal[d];
         if (p.pad_zero) {
             if (k < 1) sm1 = 0.f;
             if (k < 2) sm2 = 0.f;
@@ -163,19 +214,36 @@ __device__ __forceinline__ void waypoint_terms(const CostParams &p, const uint32
         const float a = fmaf(c_far, (sm2 - v0) + (sp2 - v0), c_near * ((sm1 - v0) + (sp1 - v0)));
         acc2 = fmaf(a, a, acc2);
     }
-    const float len_prev = sqrtf(len_prev2);
-    const float len_next = sqrtf(len_next2);
-    const float cv = grid_value<D>(p, bits, q0);
-    float gl = cv * (0.5f * (len_prev + len_next));
-    float ll = len_next;
+    WaypointPart w;
+    w.len_prev = sqrtf(len_prev2);
+    w.len_next = sqrtf(len_next2);
+    w.acc2 = acc2;
+    w.cell = grid_cell<D>(p, q0);
+    return w;
+}
+
+__device__ __forceinline__ void waypoint_finish(const CostParams &p, const WaypointPart &w, int k, float cv,
+                                                float &j_len, float &j_grid, float &j_smooth)
+{
+    float gl = cv * (0.5f * (w.len_prev + w.len_next));
+    float ll = w.len_next;
     if (k == 0) {
-        ll += len_prev;
-        gl = fmaf(p.c_start, 0.5f * len_prev, gl);
+        ll += w.len_prev;
+        gl = fmaf(p.c_start, 0.5f * w.len_prev, gl);
     }
-    if (k == W - 1) gl = fmaf(p.c_goal, 0.5f * len_next, gl);
+    if (k == p.W - 1) gl = fmaf(p.c_goal, 0.5f * w.len_next, gl);
     j_len += ll;
     j_grid += gl;
-    j_smooth += acc2;
+    j_smooth += w.acc2;
+}
+
+template <int D>
+__device__ __forceinline__ void waypoint_terms(const CostParams &p, const uint32_t *bits,
+                                               const float *row, int k, float &j_len, float &j_grid,
+                                               float &j_smooth)
+{
+    const WaypointPart w = waypoint_prepare<D>(p, row, k);
+    waypoint_finish(p, w, k, grid_value_at(p, bits, w.cell), j_len, j_grid, j_smooth);
 }
 
 // weighted total, the three terms added left to right; NaN ranks last

@@ -19,7 +19,18 @@ namespace lmcma {
 
 namespace {
 
+#ifdef LMCMA_DIAG
+// diagnostic build only: wall-clock stamps (100 MHz counter) of the phases of the last workgroup
+static __device__ unsigned long long g_generate_stamps[16];
+#define GEN_STAMP(i) st[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define GEN_STAMP(i)
+#endif
+
 constexpr int kLanes = 32;           // lanes per candidate
+// direction vectors per pass of the sampling loop: 16 float4 loads in flight per lane
+template <int J>
+constexpr int kDirectionsPerPass = J == 1 ? 16 : J == 2 ? 8 : 4;
 constexpr int kTile = 256 / kLanes;  // candidates per block pass
 
 // J = float4 chunks per lane (row stride <= 128 J floats)
@@ -35,11 +46,17 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
     const float mk = g.sc->mk;
     const uint32_t generation = g.sc->generation;
 
+#ifdef LMCMA_DIAG
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    GEN_STAMP(0);
     constexpr int LDP = J * 128;               // LDS stride of a direction vector: reads need no bounds
+    constexpr int U = kDirectionsPerPass<J>;   // direction vectors per pass of the sampling loop
+    const int mp = (g.m + U - 1) / U * U;      // rows of the LDS copies: whole passes, zero beyond k
     float *srows = smem;                       // [kTile][ld]
-    float *sV = srows + kTile * ld;            // [m][LDP] when VB_LDS, zero beyond ld
-    float *sB = sV + (VB_LDS ? g.m * LDP : 0); // [m][LDP] when VB_LDS, zero beyond ld
-    uint32_t *sbits = reinterpret_cast<uint32_t *>(sB + (VB_LDS ? g.m * LDP : 0));
+    float *sV = srows + kTile * ld;            // [mp][LDP] when VB_LDS, zero beyond ld and beyond row k
+    float *sB = sV + (VB_LDS ? mp * LDP : 0);  // [mp][LDP] when VB_LDS, likewise
+    uint32_t *sbits = reinterpret_cast<uint32_t *>(sB + (VB_LDS ? mp * LDP : 0));
 
     const int lane = threadIdx.x & (kLanes - 1);
     const int slot = threadIdx.x / kLanes;
@@ -56,8 +73,9 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
         h4[j] = reinterpret_cast<const float4 *>(g.hi)[cc];
     }
     if (VB_LDS) {
-        // All m rows, whatever k is: the copy then does not wait for the scalar load of k.
-        const int n4 = g.m * (LDP >> 2);
+        // All rows, whatever k is: the loads then do not wait for the scalar load of k (rows
+        // from k on are stored as zeros: the sampling loop below runs in whole passes).
+        const int n4 = mp * (LDP >> 2);
         const float4 *srcV = reinterpret_cast<const float4 *>(g.V);
         const float4 *srcB = reinterpret_cast<const float4 *>(g.B);
         float4 *dstV = reinterpret_cast<float4 *>(sV), *dstB = reinterpret_cast<float4 *>(sB);
@@ -76,7 +94,7 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + u * 256;
                 if (i < n4) {
-                    const bool pad = i % (LDP >> 2) >= nchunks;
+                    const bool pad = i % (LDP >> 2) >= nchunks || i / (LDP >> 2) >= k;
                     dstV[i] = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : tv[u];
                     dstB[i] = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : tb[u];
                 }
@@ -112,18 +130,20 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
             acc[j] = make_float4(mk * z[j].x, mk * z[j].y, mk * z[j].z, mk * z[j].w);
         }
+        GEN_STAMP(1);
         __syncthreads();  // staging done (first pass) / previous tile's rows consumed (later passes)
+        GEN_STAMP(2);
 
-        // four direction vectors per pass: their dot products and lane reductions are
-        // independent, so the cross-lane latency of one hides behind the others; the
-        // rank-one updates are still applied in the order t = 0, 1, 2, ...
-        constexpr int U = 4;
+        // U direction vectors per pass: all dot products are with z itself, so they and their
+        // lane reductions are independent and the cross-lane latency of one hides behind the
+        // others; the rank-one updates are still applied in the order t = 0, 1, 2, ...  With
+        // the LDS copies (zero rows from k on) a pass has no branch in it.
         for (int t0 = 0; t0 < k; t0 += U) {
             float d[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 d[u] = 0.f;
-                if (t0 + u < k) {
+                if (VB_LDS || t0 + u < k) {
                     const float4 *v = reinterpret_cast<const float4 *>(Vp + (size_t)(t0 + u) * (VB_LDS ? LDP : ld));
 #pragma unroll
                     for (int j = 0; j < J; ++j) {
@@ -142,7 +162,7 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
             for (int u = 0; u < U; ++u) d[u] = group_sum<kLanes>(d[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (t0 + u < k) {
+                if (VB_LDS || t0 + u < k) {
                     const float4 *b = reinterpret_cast<const float4 *>(Bp + (size_t)(t0 + u) * (VB_LDS ? LDP : ld));
 #pragma unroll
                     for (int j = 0; j < J; ++j) {
@@ -159,6 +179,7 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
             }
         }
 
+        GEN_STAMP(3);
         float4 *out = reinterpret_cast<float4 *>(g.rows + (size_t)c * ld);
         float4 *lrow = reinterpret_cast<float4 *>(srows + slot * ld);
 #pragma unroll
@@ -176,14 +197,27 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
             }
         }
         __syncthreads();  // the tile's rows are complete in LDS
+        GEN_STAMP(4);
 
         // ---- score ---------------------------------------------------------------------
         float j_len = 0.f, j_grid = 0.f, j_smooth = 0.f;
         const float *row = srows + slot * ld;
-        for (int w = lane; w < p.W; w += kLanes) waypoint_terms<D>(p, bits, row, w, j_len, j_grid, j_smooth);
+        // two waypoints per pass: both grid lookups (the only global loads of this half, at
+        // data-dependent addresses) are in flight together; the terms are added in waypoint order
+        for (int w0 = lane; w0 < p.W; w0 += 2 * kLanes) {
+            const int w1 = w0 + kLanes;
+            const bool has1 = w1 < p.W;
+            const WaypointPart a = waypoint_prepare<D>(p, row, w0);
+            const WaypointPart b = waypoint_prepare<D>(p, row, has1 ? w1 : w0);
+            const float ca = grid_value_at(p, bits, a.cell);
+            const float cb = grid_value_at(p, bits, b.cell);
+            waypoint_finish(p, a, w0, ca, j_len, j_grid, j_smooth);
+            if (has1) waypoint_finish(p, b, w1, cb, j_len, j_grid, j_smooth);
+        }
         j_len = group_sum<kLanes>(j_len);
         j_grid = group_sum<kLanes>(j_grid);
         j_smooth = group_sum<kLanes>(j_smooth);
+        GEN_STAMP(5);
         if (live && lane == 0) {
             p.cost[cand] = total_cost(p, j_len, j_grid, j_smooth);
             if (p.terms) {
@@ -192,7 +226,14 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
             }
         }
     }
+#ifdef LMCMA_DIAG
+    st[6] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1)
+        for (int q = 0; q < 7; ++q) g_generate_stamps[q] = st[q];
+#endif
 }
+
+#undef GEN_STAMP
 
 template <int J, int D, bool GRID_LDS, bool VB_LDS>
 hipError_t launch_t(hipStream_t s, const GenParams &g, size_t lds, int blocks)
@@ -213,7 +254,8 @@ hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds)
 {
     const int ntiles = (g.n_local + kTile - 1) / kTile;
     const size_t rows_b = (size_t)kTile * g.ld * sizeof(float);
-    const size_t vb_b = 2 * (size_t)g.m * (J * 128) * sizeof(float);  // rows padded to the lanes' reach
+    constexpr int U = kDirectionsPerPass<J>;
+    const size_t vb_b = 2 * (size_t)((g.m + U - 1) / U * U) * (J * 128) * sizeof(float);  // whole passes of padded rows
     const size_t grid_b = grid_lds ? (size_t)g.cost.grid_words * sizeof(uint32_t) : 0;
     const size_t budget = 160 * 1024;
     const bool vb_lds = rows_b + vb_b + grid_b <= budget && g.m <= 32;
@@ -244,6 +286,13 @@ hipError_t launch_d(hipStream_t s, const GenParams &g, bool grid_lds)
 }
 
 }  // namespace
+
+#ifdef LMCMA_DIAG
+extern "C" hipError_t lmcma_diag_generate_stamps(unsigned long long *out16)
+{
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_generate_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
 
 hipError_t launch_generate(hipStream_t s, const GenParams &g, int dims, bool grid_lds)
 {

@@ -215,10 +215,7 @@ __global__ __launch_bounds__(TB) void k_rank(const RankArgs r)
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            uint32_t v = row16_sum_u32(cq[q]);
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            cq[q] = v;
+            cq[q] = add_lane_xor32(add_lane_xor16(row16_sum_u32(cq[q])));
         }
         // the 16 lanes of group g carry on with candidate c0 + g
         const int gq = grp & 3;
@@ -246,13 +243,8 @@ __global__ __launch_bounds__(TB) void k_rank(const RankArgs r)
             below = (live && lane == 0) ? (uint32_t)lo : 0u;
         }
         // the four groups of a wave add their counts: lanes 0, 16, 32, 48 hold them
-        below += __shfl_xor(below, 16, 64);
-        below += __shfl_xor(below, 32, 64);
+        below = add_lane_xor32(add_lane_xor16(below));
         if (lane == 0) {
-            if (live) {
-                r.sorted_cost[rank] = value;
-                r.perm[rank] = i;
-            }
             if (wl == 0) s_below[tid >> 6] = below;
             if (recombine) {
                 const int local = i - r.first_candidate;
@@ -262,11 +254,10 @@ __global__ __launch_bounds__(TB) void k_rank(const RankArgs r)
         }
         __syncthreads();
         RANK_STAMP(3);
+        uint32_t below_total = 0;
         if (tid == 0) {
-            uint32_t total = 0;
 #pragma unroll
-            for (int w = 0; w < TB / 64; ++w) total += s_below[w];
-            r.psr_parts[blockIdx.x] = total;
+            for (int w = 0; w < TB / 64; ++w) below_total += s_below[w];
         }
 
         // ---- elite rows of this workgroup, candidates in index order
@@ -304,6 +295,12 @@ __global__ __launch_bounds__(TB) void k_rank(const RankArgs r)
                 for (int n = tid; n < N; n += TB) dst[n] = row_sums_total(s_part, N, n, pl.rg);
             }
         }
+        // the scattered results last: a workgroup barrier waits for the stores issued before it
+        if (lane == 0 && live) {
+            r.sorted_cost[rank] = value;
+            r.perm[rank] = i;
+        }
+        if (tid == 0) r.psr_parts[blockIdx.x] = below_total;
     }
 #ifdef LMCMA_DIAG
     RANK_STAMP(4);

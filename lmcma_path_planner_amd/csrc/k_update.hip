@@ -2,6 +2,8 @@
 //
 // Replaces LMCMA::update (lmcma_path_planner/src/lmcma.cpp:313-424) and invAz
 // (:449-463); the citations L/:a-b below are lines of that file.
+#include <stdlib.h>
+
 #include "update_body.hpp"
 
 namespace lmcma {
@@ -83,7 +85,15 @@ extern "C" hipError_t lmcma_diag_update_stamps(unsigned long long *out16)
 
 // workgroup size of the update for m direction vectors of N parameters: 16 lanes per
 // vector; the smallest workgroup leaves the most registers per lane
-static int threads_for_vectors(int m) { return m <= 16 ? 256 : m <= 32 ? 512 : 1024; }
+static int threads_for_vectors(int m)
+{
+    int t = m <= 16 ? 256 : m <= 32 ? 512 : 1024;
+    if (const char *f = getenv("LMCMA_HIP_UPDATE_THREADS")) {  // more threads than 16 m: they only help read the partial rows
+        const int v = atoi(f);
+        if ((v == 256 || v == 512 || v == 1024) && v >= t) t = v;
+    }
+    return t;
+}
 
 static bool update_fits_lds(int N, int m)
 {

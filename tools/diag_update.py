@@ -24,8 +24,13 @@ for g in range(60):
     su = (ctypes.c_uint64 * 16)()
     lib.lmcma_hip_diag_stamps(ctx._h, 1, sr)
     lib.lmcma_hip_diag_stamps(ctx._h, 0, su)
+    sg = (ctypes.c_uint64 * 16)()
+    lib.lmcma_hip_diag_stamps(ctx._h, 2, sg)
     if g in (0, 1, 4, 8, 15, 20, 30, 40, 59):
         rank = {rank_names[i]: (sr[9 + i] - sr[8 + i]) * 10 for i in range(4)}
         upd = {upd_names[i]: (su[1 + i] - su[i]) * 10 for i in range(5)}
         print(g, "rank (last workgroup), ns:", rank, "total", (sr[12] - sr[8]) * 10,
               "| update:", upd, "total", (su[5] - su[0]) * 10, flush=True)
+        gen_names = ["loads+philox", "barrier", "directions", "row out+barrier", "score", "cost out"]
+        print("   generate (last workgroup), ns:", {gen_names[i]: (sg[1 + i] - sg[i]) * 10 for i in range(6)},
+              "total", (sg[6] - sg[0]) * 10, flush=True)
