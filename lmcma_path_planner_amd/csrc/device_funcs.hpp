@@ -184,21 +184,30 @@ __device__ __forceinline__ WaypointPart waypoint_prepare(const CostParams &p, co
 {
     constexpr float c_far = -1.0f / 12.0f, c_near = 16.0f / 12.0f;
     const int W = p.W;
+    // The waypoint and its four neighbours, per dimension, read at clamped indices and
+    // selected afterwards: 5 D independent loads, all requested before the first use (the
+    // barrier keeps the compiler from sinking a load into the branch of its select).
+    float r0[D], rm1[D], rp1[D], rm2[D], rp2[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float *r = row + d * W;
+        r0[d] = r[k];
+        rm1[d] = r[k >= 1 ? k - 1 : 0];
+        rp1[d] = r[k + 1 < W ? k + 1 : W - 1];
+        rm2[d] = r[k >= 2 ? k - 2 : 0];
+        rp2[d] = r[k + 2 < W ? k + 2 : W - 1];
+    }
+    asm volatile("" ::: "memory");
     float q0[D];
     float len_prev2 = 0.f, len_next2 = 0.f, acc2 = 0.f;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        const float *r = row + d * W;
-        // the neighbours are read at clamped indices and selected afterwards: five
-        // independent loads, no branch around any of them
-        const float v0 = r[k];
-        const float rm1 = r[k >= 1 ? k - 1 : 0], rp1 = r[k + 1 < W ? k + 1 : W - 1];
-        const float rm2 = r[k >= 2 ? k - 2 : 0], rp2 = r[k + 2 < W ? k + 2 : W - 1];
-        const float vm1 = (k >= 1) ? rm1 : p.start[d];
-        const float vp1 = (k + 1 < W) ? rp1 : p.goal[d];
+        const float v0 = r0[d];
+        const float vm1 = (k >= 1) ? rm1[d] : p.start[d];
+        const float vp1 = (k + 1 < W) ? rp1[d] : p.goal[d];
         float sm1 = vm1, sp1 = vp1;
-        float sm2 = (k >= 2) ? rm2 : p.start[d];
-        float sp2 = (k + 2 < W) ? rp2 : p.goal[d];
+        float sm2 = (k >= 2) ? rm2[d] : p.start[d];
+        float sp2 = (k + 2 < W) ? rp2[d] : p.goal[d];
         if (p.pad_zero) {
             if (k < 1) sm1 = 0.f;
             if (k < 2) sm2 = 0.f;

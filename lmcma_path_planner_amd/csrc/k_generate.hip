@@ -140,15 +140,58 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
         // the LDS copies (zero rows from k on) a pass has no branch in it.
         for (int t0 = 0; t0 < k; t0 += U) {
             float d[U];
+            if (VB_LDS) {
+                // all reads of the pass are requested before the first product (left to itself the
+                // scheduler reuses one register quad and waits for every read in turn)
+                float4 vv[U][J];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float4 *v = reinterpret_cast<const float4 *>(Vp + (size_t)(t0 + u) * LDP);
+#pragma unroll
+                    for (int j = 0; j < J; ++j) vv[u][j] = v[j * kLanes + lane];
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    d[u] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        d[u] = fmaf(vv[u][j].x, z[j].x, d[u]);
+                        d[u] = fmaf(vv[u][j].y, z[j].y, d[u]);
+                        d[u] = fmaf(vv[u][j].z, z[j].z, d[u]);
+                        d[u] = fmaf(vv[u][j].w, z[j].w, d[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float4 *b = reinterpret_cast<const float4 *>(Bp + (size_t)(t0 + u) * LDP);
+#pragma unroll
+                    for (int j = 0; j < J; ++j) vv[u][j] = b[j * kLanes + lane];
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < U; ++u) d[u] = group_sum<kLanes>(d[u]);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        acc[j].x = fmaf(d[u], vv[u][j].x, acc[j].x);
+                        acc[j].y = fmaf(d[u], vv[u][j].y, acc[j].y);
+                        acc[j].z = fmaf(d[u], vv[u][j].z, acc[j].z);
+                        acc[j].w = fmaf(d[u], vv[u][j].w, acc[j].w);
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 d[u] = 0.f;
-                if (VB_LDS || t0 + u < k) {
-                    const float4 *v = reinterpret_cast<const float4 *>(Vp + (size_t)(t0 + u) * (VB_LDS ? LDP : ld));
+                if (t0 + u < k) {
+                    const float4 *v = reinterpret_cast<const float4 *>(Vp + (size_t)(t0 + u) * ld);
 #pragma unroll
                     for (int j = 0; j < J; ++j) {
                         const int chunk = j * kLanes + lane;
-                        if (VB_LDS || chunk < nchunks) {
+                        if (chunk < nchunks) {
                             const float4 vv = v[chunk];
                             d[u] = fmaf(vv.x, z[j].x, d[u]);
                             d[u] = fmaf(vv.y, z[j].y, d[u]);
@@ -162,12 +205,12 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
             for (int u = 0; u < U; ++u) d[u] = group_sum<kLanes>(d[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (VB_LDS || t0 + u < k) {
-                    const float4 *b = reinterpret_cast<const float4 *>(Bp + (size_t)(t0 + u) * (VB_LDS ? LDP : ld));
+                if (t0 + u < k) {
+                    const float4 *b = reinterpret_cast<const float4 *>(Bp + (size_t)(t0 + u) * ld);
 #pragma unroll
                     for (int j = 0; j < J; ++j) {
                         const int chunk = j * kLanes + lane;
-                        if (VB_LDS || chunk < nchunks) {
+                        if (chunk < nchunks) {
                             const float4 bb = b[chunk];
                             acc[j].x = fmaf(d[u], bb.x, acc[j].x);
                             acc[j].y = fmaf(d[u], bb.y, acc[j].y);
