@@ -133,6 +133,9 @@ hipError_t dalloc(T **p, size_t count)
 {
     hipError_t e = hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T) + 16);
     if (e == hipSuccess) e = hipMemset(*p, 0, count * sizeof(T) + 16);
+    // the fill runs on the null stream, which the context's own (non-blocking) stream does not
+    // wait for: finish it before anything is queued on that stream
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     return e;
 }
 
@@ -152,6 +155,7 @@ struct Arena {
         for (auto &r : req) total += r.second;
         hipError_t e = hipMalloc(base, total);
         if (e == hipSuccess) e = hipMemset(*base, 0, total);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // see dalloc
         if (e != hipSuccess) return e;
         char *p = static_cast<char *>(*base);
         for (auto &r : req) {
@@ -832,6 +836,7 @@ int lmcma_hip_opt_init(lmcma_hip_ctx *c, const double *xmean0, double sigma0)
     SampleScalars sc{(float)sigma0, 1.0f, 0, 0u};
     HIP_TRY(hipMemcpy(c->sc, &sc, sizeof(sc), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->xmean0, xmean0, N * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipStreamSynchronize(nullptr));  // the fills above: done before the context's stream is used
     c->sigma0 = sigma0;
     c->opt_ready = true;
     c->have_state = true;

@@ -221,7 +221,11 @@ def test_recombine_matches_fp64_sum(hip, oracle):
 
 
 @pytest.mark.parametrize("N,lam,m,gens,dims,W", [(64, 16, 4, 30, 2, 32), (64, 16, 16, 40, 2, 32),
-                                                 (128, 256, 16, 24, 2, 64), (36, 8, 3, 25, 3, 12)])
+                                                 (128, 256, 16, 24, 2, 64), (36, 8, 3, 25, 3, 12),
+                                                 (144, 512, 32, 40, 3, 48),    # 3-D, 48 waypoints, m = 32
+                                                 (256, 64, 48, 56, 2, 128),    # 128 waypoints, m = 48
+                                                 (33, 32, 5, 12, 3, 11),       # odd parameter count
+                                                 (288, 128, 16, 20, 3, 96)])   # 96 waypoints in 3-D
 def test_device_update_follows_oracle_generation_by_generation(hip, oracle, N, lam, m, gens, dims, W):
     """Each generation the oracle is handed the device's rows and costs; its fp64
     update (the reference's order of operations) must then agree with the device's."""
