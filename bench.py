@@ -199,7 +199,7 @@ def main():
             "config": {"workload": prob.name, "grid": "x".join(str(s) for s in prob.cells.shape),
                        "waypoints": prob.W, "n_params": prob.N, "lambda_per_gpu": lam_local,
                        "lambda_total": lam_total, "m": prob.m, "z_source": "philox4x32-10",
-                       "update": "on device, fp64", "episode_generations": EPISODE, "exchange": "all-gather costs + all-gather elite partial sums"
+                       "update": "on device, fp64", "episode_generations": EPISODE, "exchange": "all-gather of sorted local costs + all-gather of elite partial sums (N+2 doubles per rank)"
                        if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -167,10 +167,19 @@ int lmcma_hip_run(lmcma_hip_ctx *ctx, int n_generations);
 /* The same generation in pieces, for a population sharded over contexts:
  *   phase_local   : sample + evaluate own candidates  -> LMCMA_BUF_COST_LOCAL
  *   (exchange costs into LMCMA_BUF_COST_ALL of every context)
- *   phase_rank    : select over all costs + partial recombination of own elites
- *                                                    -> LMCMA_BUF_PARTIAL_LOCAL
+ *   phase_rank    : ranks of the own candidates among all costs + partial
+ *                   recombination of own elites      -> LMCMA_BUF_PARTIAL_LOCAL
  *   (exchange partial sums into LMCMA_BUF_PARTIAL_ALL, one row per context)
- *   phase_update  : LMCMA::update's remainder, identical on every context      */
+ *   phase_update  : LMCMA::update's remainder, identical on every context
+ * When the shards are equal blocks (lambda_total a multiple of lambda_local,
+ * first_candidate a multiple of lambda_local, lambda_local a multiple of 64 and
+ * at most 32768) a context exchanges its costs in ASCENDING order: phase_local
+ * also ranks the local candidates among themselves, LMCMA_BUF_COST_LOCAL holds
+ * the sorted local costs, and phase_rank merges the contexts' lists, so that a
+ * context's work does not grow with the square of the whole population
+ * (lmcma_hip_get_costs still returns the costs in candidate order).  After
+ * phase_rank LMCMA_BUF_SORTED_COST / LMCMA_BUF_PERM then hold the entries of the
+ * local candidates only.  All contexts of a population take the same path.    */
 int lmcma_hip_phase_local(lmcma_hip_ctx *ctx);
 int lmcma_hip_phase_rank(lmcma_hip_ctx *ctx);
 int lmcma_hip_phase_update(lmcma_hip_ctx *ctx, int n_partials);
@@ -198,10 +207,11 @@ int lmcma_hip_opt_get_vectors(lmcma_hip_ctx *ctx, double *pc, double *v_arr,
  * torch.distributed).  Valid until lmcma_hip_destroy.                          */
 enum {
     LMCMA_BUF_ROWS_LOCAL = 0,    /* float  [lambda_local][ld]                    */
-    LMCMA_BUF_COST_LOCAL = 1,    /* float  [lambda_local] (aliases COST_ALL)     */
+    LMCMA_BUF_COST_LOCAL = 1,    /* float  [lambda_local], this context's block of COST_ALL */
     LMCMA_BUF_COST_ALL = 2,      /* float  [lambda_total]                        */
-    LMCMA_BUF_PARTIAL_LOCAL = 3, /* double [N]                                   */
-    LMCMA_BUF_PARTIAL_ALL = 4,   /* double [max_partials][N]                     */
+    LMCMA_BUF_PARTIAL_LOCAL = 3, /* double [N + 2]: the context's elite sum, then its
+                                    success-rule count and the population's lowest cost */
+    LMCMA_BUF_PARTIAL_ALL = 4,   /* double [max_partials][N + 2], one such row per context */
     LMCMA_BUF_XMEAN = 5,         /* double [N]                                   */
     LMCMA_BUF_SORTED_COST = 6,   /* float  [lambda_total]                        */
     LMCMA_BUF_PERM = 7           /* int32  [lambda_total]                        */

@@ -91,6 +91,15 @@ struct lmcma_hip_ctx {
     int parity = 0, graph_parity = 0;
     bool warmed = false;
     unsigned long long *psr_accum = nullptr;
+    // A shard of a population that is exchanged as sorted lists (rank_merge_possible): the local
+    // costs in candidate order, the local ranking's permutation, and the keys of this / the last
+    // generation's own sorted list
+    bool merge_protocol = false;
+    float *cost_raw = nullptr;
+    int32_t *local_perm = nullptr;
+    uint32_t *key_buf[2] = {nullptr, nullptr};
+    float *best = nullptr;                      // a shard: lowest cost of the population
+    bool ranked_local_only = false;             // the last ranking covered the local candidates only
     int psr_parts_n = 0;   // per-workgroup success-rule counts the last ranking left at the head of `keys`
     int32_t *perm = nullptr;
     uint64_t *keys = nullptr;
@@ -212,6 +221,9 @@ struct Timed {
     }
 };
 
+// where the kernels leave the costs of the local candidates, in candidate order
+float *local_costs(const lmcma_hip_ctx *c) { return c->merge_protocol ? c->cost_raw : c->cost_all + c->first; }
+
 CostParams cost_params(const lmcma_hip_ctx *c, const float *rows, int n_rows, float *cost, float *terms)
 {
     CostParams p{};
@@ -251,7 +263,7 @@ int do_sample(lmcma_hip_ctx *c, const float *z)
 int do_evaluate(lmcma_hip_ctx *c)
 {
     Timed tm(c, LMCMA_K_COST);
-    CostParams p = cost_params(c, c->rows, c->nloc, c->cost_all + c->first, c->terms);
+    CostParams p = cost_params(c, c->rows, c->nloc, local_costs(c), c->terms);
     HIP_TRY(launch_cost(c->stream, p, c->D, c->grid_lds));
     return LMCMA_HIP_OK;
 }
@@ -268,15 +280,19 @@ int do_generate(lmcma_hip_ctx *c)
     g.first_candidate = (uint32_t)c->first;
     g.key0 = (uint32_t)c->cfg.seed;
     g.key1 = (uint32_t)(c->cfg.seed >> 32);
-    g.cost = cost_params(c, c->rows, c->nloc, c->cost_all + c->first, c->terms);
+    g.cost = cost_params(c, c->rows, c->nloc, local_costs(c), c->terms);
     HIP_TRY(launch_generate(c->stream, g, c->D, c->grid_lds));
     c->sampled = true;
     return LMCMA_HIP_OK;
 }
 
-UpdateArgs update_args(const lmcma_hip_ctx *c, const double *partials, int n_partials)
+// rows_with_scalars: the partial rows are partial_local / partial_all (N + 2 entries each, the
+// last two the contexts' success-rule counts and the lowest cost), else block_partials (N)
+UpdateArgs update_args(const lmcma_hip_ctx *c, const double *partials, int n_partials, bool rows_with_scalars)
 {
     UpdateArgs a{};
+    a.partial_stride = rows_with_scalars ? c->N + 2 : c->N;
+    a.scalars_in_rows = rows_with_scalars ? 1 : 0;
     a.opt = c->opt;
     a.sc = c->sc;
     a.N = c->N; a.ld = c->ld; a.lambda = c->lambda; a.m = c->m;
@@ -317,26 +333,47 @@ int do_select(lmcma_hip_ctx *c, bool with_recombine, int *rows_out)
     SelectResult res{};
     HIP_TRY(launch_select(c->stream, a, &res));
     c->psr_parts_n = res.psr_parts;
+    c->ranked_local_only = false;
     if (rows_out) *rows_out = res.partial_rows;
     c->selected = true;
     return LMCMA_HIP_OK;
 }
 
-// with_final: also reduce the block partials to partial_local (needed when the
-// partial sum leaves the context; the update can add the block partials itself)
-int do_recombine(lmcma_hip_ctx *c, bool with_final)
+// rank-ordered elite sums of the local rows -> rows of block_partials
+int do_recombine(lmcma_hip_ctx *c)
 {
     Timed tm(c, LMCMA_K_RECOMBINE);
     HIP_TRY(launch_recombine(c->stream, c->rows, c->ld, c->N, c->first, c->nloc, c->perm, c->weights,
-                             c->mu, c->block_partials, with_final ? c->partial_local : nullptr,
-                             update_threads(c->N, std::min(c->m, LMCMA_HIP_MAX_VECTORS))));
+                             c->mu, c->block_partials));
     return LMCMA_HIP_OK;
 }
 
-int do_update(lmcma_hip_ctx *c, const double *partials, int n_partials)
+// block_partials -> partial_local (needed when the partial sum leaves the context; the
+// update can add the block partials itself).  with_scalars: also the context's success-rule
+// count and the lowest cost, entries N and N + 1 of the row.
+int do_recombine_final(lmcma_hip_ctx *c, int rows, bool with_scalars)
+{
+    Timed tm(c, LMCMA_K_RECOMBINE);
+    FinalExtras x{};
+    x.psr_parts = reinterpret_cast<const uint32_t *>(c->keys);
+    x.n_parts = c->psr_parts_n;
+    x.psr_accum = c->ranked_local_only ? nullptr : c->psr_accum;
+    // a context that ranked the whole population holds the whole count: only the first one reports it
+    x.count_psr = (c->ranked_local_only || c->first == 0) ? 1 : 0;
+    x.best = c->ranked_local_only ? c->best : c->sorted_cost;
+    // A context whose row goes into an exchange may add its rows with any (fixed) workgroup size;
+    // one that feeds its own update must use the update's, so that reducing first and updating
+    // from the one row gives the same bits as updating from the block rows.
+    const int threads = c->merge_protocol ? 1024 : update_threads(c->N, std::min(c->m, LMCMA_HIP_MAX_VECTORS));
+    HIP_TRY(launch_recombine_final(c->stream, c->block_partials, rows, c->N, c->partial_local, threads,
+                                   with_scalars ? &x : nullptr));
+    return LMCMA_HIP_OK;
+}
+
+int do_update(lmcma_hip_ctx *c, const double *partials, int n_partials, bool rows_with_scalars)
 {
     Timed tm(c, LMCMA_K_UPDATE);
-    HIP_TRY(launch_update(c->stream, update_args(c, partials, n_partials)));
+    HIP_TRY(launch_update(c->stream, update_args(c, partials, n_partials, rows_with_scalars)));
     return LMCMA_HIP_OK;
 }
 
@@ -351,9 +388,9 @@ int one_generation(lmcma_hip_ctx *c)
     }
     int rows = 0;
     if ((rc = do_select(c, true, &rows)) != LMCMA_HIP_OK) return rc;
-    if (rows > 0) return do_update(c, c->block_partials, rows);
-    if ((rc = do_recombine(c, false)) != LMCMA_HIP_OK) return rc;
-    return do_update(c, c->block_partials, recombine_num_blocks(c->mu));
+    if (rows > 0) return do_update(c, c->block_partials, rows, false);
+    if ((rc = do_recombine(c)) != LMCMA_HIP_OK) return rc;
+    return do_update(c, c->block_partials, recombine_num_blocks(c->mu), false);
 }
 
 int check_ctx(const lmcma_hip_ctx *c)
@@ -459,7 +496,8 @@ int lmcma_hip_create(const lmcma_hip_config *cfg, lmcma_hip_ctx **out)
     ar.add(&c->xmean_f, ld);
     ar.add(&c->lo_f, ld);
     ar.add(&c->hi_f, ld);
-    ar.add(&c->partial_local, N);
+    ar.add(&c->partial_local, N + 2);
+    ar.add(&c->best, 1);
     ar.add(&c->V_f, m * ld);
     ar.add(&c->B_f, m * ld);
     ar.add(&c->pc_arr, m * N);
@@ -470,7 +508,14 @@ int lmcma_hip_create(const lmcma_hip_config *cfg, lmcma_hip_ctx **out)
     ar.add(&c->sorted_buf[1], lam + 4);
     ar.add(&c->perm, lam);
     ar.add(&c->keys, select_workspace_bytes(c->lambda) / sizeof(uint64_t) + 1);
-    ar.add(&c->partial_all, (size_t)kMaxPartials * N);
+    ar.add(&c->partial_all, (size_t)kMaxPartials * (N + 2));
+    c->merge_protocol = rank_merge_possible(c->lambda, c->nloc, c->first);
+    if (c->merge_protocol) {
+        ar.add(&c->cost_raw, nloc);
+        ar.add(&c->local_perm, nloc);
+        ar.add(&c->key_buf[0], nloc);
+        ar.add(&c->key_buf[1], nloc);
+    }
     ar.add(&c->block_partials,
            (size_t)std::max(recombine_num_blocks(c->mu), select_max_partial_rows(c->first, c->nloc)) * N);
     ar.add(&c->terms, nloc * 3);
@@ -666,6 +711,9 @@ int lmcma_hip_evaluate(lmcma_hip_ctx *c)
     if (!c->grid) return fail(LMCMA_HIP_ERR_STATE, "set_grid must come first");
     if (!c->sampled) return fail(LMCMA_HIP_ERR_STATE, "sample must come first");
     int rc = do_evaluate(c);
+    if (rc == LMCMA_HIP_OK && c->merge_protocol)  // the stepwise calls rank the costs in candidate order
+        HIP_TRY(hipMemcpyAsync(c->cost_all + c->first, c->cost_raw, c->nloc * sizeof(float), hipMemcpyDeviceToDevice,
+                               c->stream));
     if (rc == LMCMA_HIP_OK && c->nloc == c->lambda) c->costs_ready = true;
     return rc;
 }
@@ -706,7 +754,8 @@ int lmcma_hip_recombine(lmcma_hip_ctx *c, const double *weights, double *xmean_o
         c->have_weights = true;
     }
     if (!c->have_weights) return fail(LMCMA_HIP_ERR_STATE, "no recombination weights set");
-    int rc = do_recombine(c, true);
+    int rc = do_recombine(c);
+    if (rc == LMCMA_HIP_OK) rc = do_recombine_final(c, recombine_num_blocks(c->mu), false);
     if (rc != LMCMA_HIP_OK) return rc;
     if (xmean_out)
         HIP_TRY(hipMemcpyAsync(xmean_out, c->partial_local, c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -734,7 +783,7 @@ int lmcma_hip_get_costs(lmcma_hip_ctx *c, int first_local, int count, double *ou
     if (!out || first_local < 0 || count < 1 || first_local + count > c->nloc)
         return fail(LMCMA_HIP_ERR_ARG, "bad candidate range");
     std::vector<float> tmp(count);
-    HIP_TRY(hipMemcpyAsync(tmp.data(), c->cost_all + c->first + first_local, count * sizeof(float),
+    HIP_TRY(hipMemcpyAsync(tmp.data(), local_costs(c) + first_local, count * sizeof(float),
                            hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < count; ++i) out[i] = (double)tmp[i];
@@ -909,10 +958,24 @@ int lmcma_hip_phase_local(lmcma_hip_ctx *c)
     if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
     if (!c->grid) return fail(LMCMA_HIP_ERR_STATE, "set_grid must come first");
     if (c->cfg.z_source != LMCMA_Z_PHILOX) return fail(LMCMA_HIP_ERR_STATE, "phases need z_source PHILOX");
-    if (c->fused) return do_generate(c);
-    int rc = do_sample(c, nullptr);
-    if (rc != LMCMA_HIP_OK) return rc;
-    return do_evaluate(c);
+    int rc;
+    if (c->fused) {
+        rc = do_generate(c);
+    } else {
+        rc = do_sample(c, nullptr);
+        if (rc == LMCMA_HIP_OK) rc = do_evaluate(c);
+    }
+    if (rc != LMCMA_HIP_OK || !c->merge_protocol) return rc;
+    // a shard exchanges its costs in ascending order: rank the local candidates among themselves
+    Timed tm(c, LMCMA_K_SELECT);
+    SelectArgs a{};
+    a.cost_all = c->cost_raw;
+    a.lambda = c->nloc;
+    a.keys_ws = c->keys;
+    a.sorted_cost = c->cost_all + c->first;
+    a.perm = c->local_perm;
+    HIP_TRY(launch_select(c->stream, a, nullptr));
+    return LMCMA_HIP_OK;
 }
 
 int lmcma_hip_phase_rank(lmcma_hip_ctx *c)
@@ -920,15 +983,39 @@ int lmcma_hip_phase_rank(lmcma_hip_ctx *c)
     CTX_TRY(c);
     if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
     int rows = 0;
+    if (c->merge_protocol) {
+        if (!c->have_weights) return fail(LMCMA_HIP_ERR_STATE, "no recombination weights set");
+        {
+            Timed tm(c, LMCMA_K_SELECT);
+            c->parity ^= 1;
+            c->sorted_cost = c->sorted_buf[c->parity];
+            MergeArgs a{};
+            a.lists = c->cost_all;
+            a.lambda = c->lambda; a.n_local = c->nloc; a.first_candidate = c->first;
+            a.local_perm = c->local_perm;
+            a.sorted_cost = c->sorted_cost;
+            a.perm = c->perm;
+            a.opt = c->opt;
+            a.prev_own = c->key_buf[c->parity ^ 1];
+            a.own_out = c->key_buf[c->parity];
+            a.psr_parts = reinterpret_cast<uint32_t *>(c->keys);
+            a.best_out = c->best;
+            a.rows = c->rows; a.ld = c->ld; a.N = c->N;
+            a.weights = c->weights; a.mu = c->mu;
+            a.block_partials = c->block_partials;
+            HIP_TRY(launch_rank_merge(c->stream, a, &rows));
+            c->psr_parts_n = rows;
+            c->ranked_local_only = true;
+            c->selected = true;
+        }
+        return do_recombine_final(c, rows, true);
+    }
     int rc = do_select(c, true, &rows);
     if (rc != LMCMA_HIP_OK) return rc;
-    if (rows > 0) {
-        Timed tm(c, LMCMA_K_RECOMBINE);
-        HIP_TRY(launch_recombine_final(c->stream, c->block_partials, rows, c->N, c->partial_local,
-                                       update_threads(c->N, std::min(c->m, LMCMA_HIP_MAX_VECTORS))));
-        return LMCMA_HIP_OK;
-    }
-    return do_recombine(c, true);
+    if (rows > 0) return do_recombine_final(c, rows, true);
+    rc = do_recombine(c);
+    if (rc != LMCMA_HIP_OK) return rc;
+    return do_recombine_final(c, recombine_num_blocks(c->mu), true);
 }
 
 int lmcma_hip_phase_update(lmcma_hip_ctx *c, int n_partials)
@@ -937,8 +1024,8 @@ int lmcma_hip_phase_update(lmcma_hip_ctx *c, int n_partials)
     if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
     if (n_partials < 0 || n_partials > kMaxPartials) return fail(LMCMA_HIP_ERR_ARG, "n_partials must be in [0, 64]");
     // n_partials = 0: a single context, its own partial sum is the new mean
-    if (n_partials == 0) return do_update(c, c->partial_local, 1);
-    return do_update(c, c->partial_all, n_partials);
+    if (n_partials == 0) return do_update(c, c->partial_local, 1, true);
+    return do_update(c, c->partial_all, n_partials, true);
 }
 
 int lmcma_hip_opt_get(lmcma_hip_ctx *c, lmcma_hip_opt_summary *summary, double *xmean)
@@ -984,8 +1071,8 @@ int lmcma_hip_buffer(lmcma_hip_ctx *c, int which, void **device_ptr, size_t *byt
         case LMCMA_BUF_ROWS_LOCAL: p = c->rows; b = (size_t)c->nloc * c->ld * sizeof(float); break;
         case LMCMA_BUF_COST_LOCAL: p = c->cost_all + c->first; b = (size_t)c->nloc * sizeof(float); break;
         case LMCMA_BUF_COST_ALL: p = c->cost_all; b = (size_t)c->lambda * sizeof(float); break;
-        case LMCMA_BUF_PARTIAL_LOCAL: p = c->partial_local; b = (size_t)c->N * sizeof(double); break;
-        case LMCMA_BUF_PARTIAL_ALL: p = c->partial_all; b = (size_t)kMaxPartials * c->N * sizeof(double); break;
+        case LMCMA_BUF_PARTIAL_LOCAL: p = c->partial_local; b = (size_t)(c->N + 2) * sizeof(double); break;
+        case LMCMA_BUF_PARTIAL_ALL: p = c->partial_all; b = (size_t)kMaxPartials * (c->N + 2) * sizeof(double); break;
         case LMCMA_BUF_XMEAN: p = c->xmean; b = (size_t)c->N * sizeof(double); break;
         case LMCMA_BUF_SORTED_COST: p = c->sorted_cost; b = (size_t)c->lambda * sizeof(float); break;
         case LMCMA_BUF_PERM: p = c->perm; b = (size_t)c->lambda * sizeof(int32_t); break;

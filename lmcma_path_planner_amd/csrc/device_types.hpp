@@ -111,17 +111,51 @@ struct SelectResult {
 hipError_t launch_select(hipStream_t s, const SelectArgs &a, SelectResult *res);
 hipError_t launch_select_sort(hipStream_t s, const SelectArgs &a);
 
+// One shard of a population of G = lambda / n_local contexts, after the exchange of the
+// contexts' ASCENDING local costs (`lists`, context g's block at g n_local): global ranks of
+// the local candidates by merging, their share of the success-rule count, the elite rows
+// (one row of block_partials per workgroup, *rows_out of them) and the population's lowest
+// cost.  sorted_cost / perm receive the local candidates' entries only.
+struct MergeArgs {
+    const float *lists;
+    int lambda, n_local, first_candidate;
+    const int32_t *local_perm;    // [n_local] local candidate at local position p (the local ranking's perm)
+    float *sorted_cost;
+    int32_t *perm;
+    const OptScalars *opt;        // success-rule count when opt->itr > 0
+    const uint32_t *prev_own;     // [n_local] keys of this context's list of last generation
+    uint32_t *own_out;            // [n_local] keys of this context's list of this generation
+    uint32_t *psr_parts;          // [n_local / 32] per-workgroup success-rule counts
+    float *best_out;
+    const float *rows;
+    int ld, N;
+    const double *weights;
+    int mu;
+    double *block_partials;
+};
+bool rank_merge_possible(int lambda, int n_local, int first_candidate);
+hipError_t launch_rank_merge(hipStream_t s, const MergeArgs &a, int *rows_out);
+
 constexpr int kRecombineRanksPerBlock = 32;
 int recombine_num_blocks(int mu);
 hipError_t launch_recombine(hipStream_t s, const float *rows, int ld, int N, int first_candidate,
                             int n_local, const int32_t *perm, const double *weights, int mu,
-                            double *block_partials, double *partial_local, int threads);
+                            double *block_partials);
 
 // partial_local[N] = sum of the first `rows` rows of block_partials, in the order in which a
 // workgroup of `threads` threads adds them (the update adds its partial rows in the same
 // order, so reducing first and updating from the one row gives the same bits)
+// extras != nullptr: partial_local has N + 2 entries, the last two being the context's
+// success-rule count (psr_parts[0 .. n_parts) + *psr_accum, or 0 when !count_psr) and *best
+struct FinalExtras {
+    const uint32_t *psr_parts;
+    int n_parts;
+    const unsigned long long *psr_accum;
+    int count_psr;
+    const float *best;
+};
 hipError_t launch_recombine_final(hipStream_t s, const double *block_partials, int rows, int N,
-                                  double *partial_local, int threads);
+                                  double *partial_local, int threads, const FinalExtras *extras);
 // workgroup size the update uses for m direction vectors of N parameters
 int update_threads(int N, int m);
 
@@ -129,8 +163,11 @@ struct UpdateArgs {
     OptScalars *opt;
     SampleScalars *sc;
     int N, ld, lambda, m;
-    const double *partials;  // [n_partials][N]
-    int n_partials;
+    const double *partials;  // [n_partials][partial_stride], the first N entries of a row are summed
+    int n_partials, partial_stride;
+    // 1: entries [N] (success-rule count) and [N + 1] (lowest cost) of the rows carry the scalars
+    // of a sharded population; 0: they come from psr_accum / psr_parts / sorted_cost[0]
+    int scalars_in_rows;
     const float *sorted_cost;   // [lambda] this generation, ascending
     // success rule: sum over this generation's candidates of #{previous costs below it} =
     // *psr_accum (read and zeroed by the update) + psr_parts[0 .. n_psr_parts)

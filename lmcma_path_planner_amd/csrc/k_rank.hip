@@ -309,6 +309,196 @@ __global__ __launch_bounds__(TB) void k_rank(const RankArgs r)
 #endif
 }
 
+// ---- one shard of a population: global ranks of the local candidates by merging ----------
+// In a job of G contexts each context first ranks its own n_local candidates among
+// themselves (k_rank on the local costs) and puts its ASCENDING costs into its block of the
+// exchanged cost vector.  After the exchange every context holds G sorted lists, and the
+// global rank of its element at local position p is
+//     p + sum over lower contexts of #{their costs <= x} + sum over higher contexts of #{their costs < x}
+// (ties across contexts resolve by context order = candidate index order, like the stable
+// sort of the whole population).  The success rule needs the number of pairs (previous cost
+// j, current cost i) with j < i, over the whole population; a context counts the pairs of ITS
+// previous costs (last generation's own list, kept as keys): for its previous element y,
+// lambda - sum over all contexts of #{their current costs <= y}.  Per element that is 2 G
+// searches of 3 rounds (16 lanes probe a list 16 ways per round; the lists pass through LDS
+// once), instead of lambda compares: the work per context no longer grows with the square of
+// the population.  sorted_cost / perm receive the entries of the
+// local candidates only; the workgroup's elite rows go to one row of block_partials.
+struct RankMergeArgs {
+    const float *lists;           // [G][n_local] ascending costs of every context (the exchanged vector)
+    int lambda, n_local, me;      // lambda = G n_local; me = index of this context
+    const int32_t *local_perm;    // [n_local] local candidate at local position p
+    float *sorted_cost;
+    int32_t *perm;
+    const OptScalars *opt;        // success-rule count when opt->itr > 0
+    const uint32_t *prev_own;     // [n_local] this context's list of last generation, as keys
+    uint32_t *own_out;            // [n_local] this context's list of this generation, as keys
+    uint32_t *psr_parts;          // [gridDim.x]
+    float *best_out;              // lowest cost of the population
+    const float *rows;
+    int ld, N;
+    const double *weights;
+    int mu;
+    double *block_partials;       // [gridDim.x][N]
+};
+
+constexpr int kMergeChunk = 32768;  // keys in LDS at a time (128 KiB)
+
+// number of entries of the ascending key list s[0..n) that are below x (or_equal: at or below),
+// found by the 16 lanes of a group together; every lane returns the count
+__device__ __forceinline__ int group_search16(const uint32_t *s, int n, uint32_t x, bool or_equal, int lane, int shift)
+{
+    int lo = 0, len = n;  // the answer lies in [lo, lo + len]
+    while (len > 0) {
+        const int chunk = (len + 15) >> 4;
+        const int p = lo + (lane + 1) * chunk - 1;
+        bool hit = false;
+        if (p < lo + len) {
+            const uint32_t k = s[p];
+            hit = or_equal ? k <= x : k < x;
+        }
+        const unsigned long long mask = __ballot(hit);
+        const int q = __popcll((mask >> shift) & 0xFFFFull);  // probes below, of this group's 16
+        const int end = lo + len;
+        lo += q * chunk;
+        len = chunk - 1 < end - lo ? chunk - 1 : end - lo;
+    }
+    return lo;
+}
+
+template <int TB>
+__global__ __launch_bounds__(TB) void k_rank_merge(const RankMergeArgs r)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+    constexpr int CPB = TB / 16;
+    const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
+    const int lambda = r.lambda, N = r.N, nl = r.n_local;
+    const int G = lambda / nl;
+    const bool psr = r.opt != nullptr && r.opt->itr > 0;
+
+    double *s_part = s_dyn;                               // [rg][N]
+    double *s_w = s_part + (((TB > N ? TB : N) + 1) & ~1);  // [CPB]
+    int *s_cand = reinterpret_cast<int *>(s_w + CPB);     // [CPB] local candidate of each element
+    uint32_t *s_below = reinterpret_cast<uint32_t *>(s_cand + CPB);  // [TB / 64]
+    uint32_t *s_key = s_below + 16;                       // [min(lambda, kMergeChunk)]
+
+    const int p = blockIdx.x * CPB + grp;                 // local position of this group's element
+    const bool live = p < nl;
+    const int pc = live ? p : nl - 1;
+    const uint32_t mine = order_bits(r.lists[(size_t)r.me * nl + pc]);
+    const uint32_t yprev = psr ? r.prev_own[pc] : 0u;
+    const int cand = r.local_perm[pc];
+
+    const int lists_per_chunk = kMergeChunk / nl > 0 ? kMergeChunk / nl : 1;  // n_local <= kMergeChunk
+    int rank = pc, at_or_below_prev = 0;
+    uint32_t kmin = ~0u;
+    {
+        for (int g0 = 0; g0 < G; g0 += lists_per_chunk) {
+            const int ng = G - g0 < lists_per_chunk ? G - g0 : lists_per_chunk;
+            const int n4 = (ng * nl + 3) >> 2, base4 = (g0 * nl) >> 2;  // n_local is a multiple of 4
+            __syncthreads();  // the previous chunk has been searched
+            for (int t0 = tid; t0 < n4; t0 += 8 * TB) {
+                uint4 kk[8];
+                {
+                    float4 c[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int t = t0 + u * TB;
+                        c[u] = reinterpret_cast<const float4 *>(r.lists)[base4 + (t < n4 ? t : n4 - 1)];
+                    }
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        kk[u] = make_uint4(order_bits(c[u].x), order_bits(c[u].y), order_bits(c[u].z), order_bits(c[u].w));
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = t0 + u * TB;
+                    if (t < n4) reinterpret_cast<uint4 *>(s_key)[t] = kk[u];
+                }
+            }
+            __syncthreads();
+            for (int g = g0; g < g0 + ng; ++g) {
+                const uint32_t *s = s_key + (size_t)(g - g0) * nl;
+                if (blockIdx.x == 0 && tid == 0) kmin = min(kmin, s[0]);  // a list's first entry is its lowest
+                if (g != r.me) rank += group_search16(s, nl, mine, g < r.me, lane, tid & 48);
+                if (psr) at_or_below_prev += group_search16(s, nl, yprev, true, lane, tid & 48);
+            }
+        }
+    }
+    const float value = order_bits_inv(mine);
+    // pairs (this context's previous element, any current cost above it)
+    uint32_t bsum = (psr && live && lane == 0) ? (uint32_t)(lambda - at_or_below_prev) : 0u;
+    bsum = add_lane_xor32(add_lane_xor16(bsum));
+    if (wl == 0) s_below[tid >> 6] = bsum;
+    if (lane == 0) {
+        s_w[grp] = (live && rank < r.mu) ? r.weights[rank] : 0.0;
+        s_cand[grp] = cand;
+    }
+    __syncthreads();
+    uint32_t below_total = 0;
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 0; w < TB / 64; ++w) below_total += s_below[w];
+    }
+    // ---- elite rows of this workgroup, elements in local order
+    const RowSumPlan pl = row_sum_plan(N, TB);
+    const int ch = (CPB + pl.rg - 1) / pl.rg;
+    const int rgi = tid / pl.cw, n0 = tid % pl.cw;
+    if (rgi < pl.rg) {
+        for (int n = n0; n < N; n += pl.cw) {
+            double acc = 0.0;
+            for (int u0 = 0; u0 < ch; u0 += 8) {
+                float x[8];
+                double w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = rgi * ch + u0 + u;
+                    const bool in = u0 + u < ch && c < CPB;
+                    w[u] = in ? s_w[c] : 0.0;
+                    x[u] = r.rows[(size_t)s_cand[in ? c : 0] * r.ld + n];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (w[u] != 0.0) acc += w[u] * (double)x[u];
+            }
+            s_part[rgi * N + n] = acc;
+        }
+    }
+    __syncthreads();
+    {
+        double *dst = r.block_partials + (size_t)blockIdx.x * N;
+        for (int n = tid; n < N; n += TB) dst[n] = row_sums_total(s_part, N, n, pl.rg);
+    }
+    if (lane == 0 && live) {
+        r.sorted_cost[rank] = value;
+        r.perm[rank] = r.me * nl + cand;
+        r.own_out[p] = mine;  // this context's list, for the next generation's success rule
+    }
+    if (tid == 0) {
+        r.psr_parts[blockIdx.x] = below_total;
+        if (blockIdx.x == 0) *r.best_out = order_bits_inv(kmin);
+    }
+}
+
+template <int TB>
+hipError_t launch_rank_merge_t(hipStream_t s, const RankMergeArgs &r, int blocks)
+{
+    constexpr int CPB = TB / 16;
+    const int keys = r.lambda < kMergeChunk ? r.lambda : kMergeChunk;
+    const size_t lds = ((size_t)(((TB > r.N ? TB : r.N) + 1) & ~1) + CPB) * sizeof(double) + (size_t)CPB * sizeof(int) +
+                       (size_t)(16 + keys) * sizeof(uint32_t);
+    static size_t configured = 48 * 1024;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rank_merge<TB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL((k_rank_merge<TB>), dim3(blocks), dim3(TB), lds, s, r);
+    return hipGetLastError();
+}
+
 template <int TB>
 hipError_t launch_rank_t(hipStream_t s, const RankArgs &r, int blocks, size_t lds)
 {
@@ -357,12 +547,41 @@ int select_max_partial_rows(int first_candidate, int n_local)
     return (first_candidate + n_local + cpb - 1) / cpb - first_candidate / cpb;
 }
 
+bool rank_merge_possible(int lambda, int n_local, int first_candidate)
+{
+    return n_local < lambda && n_local % 64 == 0 && lambda % n_local == 0 && first_candidate % n_local == 0 &&
+           n_local <= kMergeChunk && getenv("LMCMA_HIP_NO_MERGE_RANK") == nullptr;
+}
+
+hipError_t launch_rank_merge(hipStream_t s, const MergeArgs &a, int *rows_out)
+{
+    if (!rank_merge_possible(a.lambda, a.n_local, a.first_candidate)) return hipErrorInvalidValue;
+    RankMergeArgs r{};
+    r.lists = a.lists;
+    r.lambda = a.lambda; r.n_local = a.n_local; r.me = a.first_candidate / a.n_local;
+    r.local_perm = a.local_perm;
+    r.sorted_cost = a.sorted_cost;
+    r.perm = a.perm;
+    r.opt = a.opt;
+    r.prev_own = a.prev_own;
+    r.own_out = a.own_out;
+    r.psr_parts = a.psr_parts;
+    r.best_out = a.best_out;
+    r.rows = a.rows; r.ld = a.ld; r.N = a.N;
+    r.weights = a.weights; r.mu = a.mu;
+    r.block_partials = a.block_partials;
+    const int blocks = (a.n_local + 31) / 32;
+    if (rows_out) *rows_out = blocks;
+    return launch_rank_merge_t<512>(s, r, blocks);
+}
+
 hipError_t launch_select(hipStream_t s, const SelectArgs &a, SelectResult *res)
 {
     SelectResult out{};
     if (res) *res = out;
     const int lambda = a.lambda;
     if (lambda <= 0) return hipErrorInvalidValue;
+
     if (!select_by_counting(lambda)) return launch_select_sort(s, a);
 
     const OptScalars *opt = (a.prev_sorted && a.psr_accum) ? a.opt : nullptr;

@@ -52,15 +52,30 @@ __global__ __launch_bounds__(256) void k_recombine_partial(const float *__restri
     }
 }
 
-// partial_local[n] = sum of the rows of block_partials, in the order of row_sums_to_lds
+// partial_local[n] = sum of the rows of block_partials, in the order of row_sums_to_lds.
+// With x.best != nullptr the row gets two more entries, the scalars a context contributes to
+// the update of a sharded population: [N] its success-rule count, [N + 1] the lowest cost.
 __global__ __launch_bounds__(1024) void k_recombine_final(const double *__restrict__ block_partials,
                                                           int nblocks, int N,
-                                                          double *__restrict__ partial_local)
+                                                          double *__restrict__ partial_local, const FinalExtras x)
 {
     __shared__ double s_red[2048];  // row_sum_lds_doubles(N <= 512, T <= 1024)
-    row_sums_to_lds(block_partials, nblocks, N, (int)blockDim.x, s_red);
+    row_sums_to_lds(block_partials, nblocks, N, N, (int)blockDim.x, s_red);
     __syncthreads();
     for (int n = threadIdx.x; n < N; n += blockDim.x) partial_local[n] = row_sums_total(s_red, N, n, row_sum_groups(N, (int)blockDim.x));
+    if (x.best != nullptr && threadIdx.x < 64) {
+        unsigned long long v = 0ull;
+        if (x.count_psr) {
+            for (int b = threadIdx.x; b < x.n_parts; b += 64) v += x.psr_parts[b];
+            if (threadIdx.x == 0 && x.psr_accum != nullptr) v += *x.psr_accum;
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
+        if (threadIdx.x == 0) {
+            partial_local[N] = (double)v;
+            partial_local[N + 1] = (double)*x.best;
+        }
+    }
 }
 
 // ---- update, stand-alone ------------------------------------------------------------
@@ -109,7 +124,7 @@ int recombine_num_blocks(int mu)
 
 hipError_t launch_recombine(hipStream_t s, const float *rows, int ld, int N, int first_candidate,
                             int n_local, const int32_t *perm, const double *weights, int mu,
-                            double *block_partials, double *partial_local, int threads)
+                            double *block_partials)
 {
     if (mu <= 0 || N <= 0 || (ld & 3) || ld > 512) return hipErrorInvalidValue;
     const int nb = recombine_num_blocks(mu);
@@ -117,17 +132,16 @@ hipError_t launch_recombine(hipStream_t s, const float *rows, int ld, int N, int
     const size_t lds = (size_t)nslots * ld * sizeof(double);
     hipLaunchKernelGGL(k_recombine_partial, dim3(nb), dim3(256), lds, s, rows, ld, N, first_candidate,
                        n_local, perm, weights, mu, block_partials);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || !partial_local) return e;
-    hipLaunchKernelGGL(k_recombine_final, dim3(1), dim3(threads), 0, s, block_partials, nb, N, partial_local);
     return hipGetLastError();
 }
 
 hipError_t launch_recombine_final(hipStream_t s, const double *block_partials, int rows, int N,
-                                  double *partial_local, int threads)
+                                  double *partial_local, int threads, const FinalExtras *extras)
 {
     if (rows < 1 || N < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_recombine_final, dim3(1), dim3(threads), 0, s, block_partials, rows, N, partial_local);
+    FinalExtras x{};
+    if (extras) x = *extras;
+    hipLaunchKernelGGL(k_recombine_final, dim3(1), dim3(threads), 0, s, block_partials, rows, N, partial_local, x);
     return hipGetLastError();
 }
 

@@ -48,11 +48,11 @@ struct RowSumBatch {
     double2 v[kRowBatch];
 };
 
-__device__ __forceinline__ void row_sums_begin(const double *src, int count, int N, int T, RowSumBatch &first)
+__device__ __forceinline__ void row_sums_begin(const double *src, int count, int N, int stride, int T, RowSumBatch &first)
 {
 #pragma unroll
     for (int u = 0; u < kRowBatch; ++u) first.v[u] = make_double2(0.0, 0.0);
-    if ((N & 1) != 0) return;
+    if (((N | stride) & 1) != 0) return;
     const RowSumPlan pl = row_sum_plan2(N, T);
     const int r = __builtin_amdgcn_readfirstlane((int)threadIdx.x / pl.cw);
     const int n = 2 * ((int)threadIdx.x % pl.cw);
@@ -60,16 +60,16 @@ __device__ __forceinline__ void row_sums_begin(const double *src, int count, int
 #pragma unroll
     for (int u = 0; u < kRowBatch; ++u) {
         const int b = r + u * pl.rg;  // wave-uniform
-        if (b < count) first.v[u] = *reinterpret_cast<const double2 *>(src + (size_t)b * N + n);
+        if (b < count) first.v[u] = *reinterpret_cast<const double2 *>(src + (size_t)b * stride + n);
     }
 }
 
 template <bool HAVE_FIRST>
-__device__ __forceinline__ void row_sums_to_lds_t(const double *src, int count, int N, int T, double *s_red,
-                                                  const RowSumBatch &first)
+__device__ __forceinline__ void row_sums_to_lds_t(const double *src, int count, int N, int stride, int T,
+                                                  double *s_red, const RowSumBatch &first)
 {
     constexpr int kBatch = kRowBatch;
-    if ((N & 1) == 0) {
+    if (((N | stride) & 1) == 0) {
         const RowSumPlan pl = row_sum_plan2(N, T);
         // cw is a multiple of 64 (or the whole workgroup), so r is the same in every lane of a wave
         const int r = __builtin_amdgcn_readfirstlane((int)threadIdx.x / pl.cw);
@@ -87,7 +87,7 @@ __device__ __forceinline__ void row_sums_to_lds_t(const double *src, int count, 
                     for (int u = 0; u < kBatch; ++u) {
                         const int b = b0 + u * pl.rg;  // wave-uniform
                         v[u] = make_double2(0.0, 0.0);
-                        if (b < count) v[u] = *reinterpret_cast<const double2 *>(src + (size_t)b * N + n);
+                        if (b < count) v[u] = *reinterpret_cast<const double2 *>(src + (size_t)b * stride + n);
                     }
                     asm volatile("" ::: "memory");  // all loads of the batch are issued before the first add
                 }
@@ -115,7 +115,7 @@ __device__ __forceinline__ void row_sums_to_lds_t(const double *src, int count, 
             for (int u = 0; u < kBatch; ++u) {
                 const int b = b0 + u * pl.rg;  // wave-uniform
                 v[u] = 0.0;
-                if (b < count) v[u] = src[(size_t)b * N + n];
+                if (b < count) v[u] = src[(size_t)b * stride + n];
             }
             asm volatile("" ::: "memory");
 #pragma unroll
@@ -126,10 +126,10 @@ __device__ __forceinline__ void row_sums_to_lds_t(const double *src, int count, 
     }
 }
 
-__device__ __forceinline__ void row_sums_to_lds(const double *src, int count, int N, int T, double *s_red)
+__device__ __forceinline__ void row_sums_to_lds(const double *src, int count, int N, int stride, int T, double *s_red)
 {
     RowSumBatch none;
-    row_sums_to_lds_t<false>(src, count, N, T, s_red, none);
+    row_sums_to_lds_t<false>(src, count, N, stride, T, s_red, none);
 }
 
 // row groups row_sums_to_lds uses, and the doubles of LDS it needs
@@ -274,7 +274,11 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, 
             const int b = wl + 64 * u;
             pp[u] = a.psr_parts[b < a.n_psr_parts ? b : 0];
         }
-        if (tid == stid) {
+        if (a.scalars_in_rows) {
+            // a sharded population: every context's row carries its count and the lowest cost
+            if (wl < a.n_partials) psr_lane = (unsigned long long)a.partials[(size_t)wl * a.partial_stride + N];
+            if (tid == stid) best_in = (float)a.partials[N + 1];
+        } else if (tid == stid) {
             psr_lane = *a.psr_accum;
             best_in = a.sorted_cost[0];  // this generation's lowest cost
         }
@@ -293,7 +297,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, 
     // L/:316-329: the rank-ordered partial sums of the new mean; the slot bookkeeping and the
     // step-size rule below run while these loads are in flight
     RowSumBatch first_rows;
-    row_sums_begin(a.partials, a.n_partials, N, T, first_rows);
+    row_sums_begin(a.partials, a.n_partials, N, a.partial_stride, T, first_rows);
     asm volatile("" ::: "memory");  // no load above is moved below this point
     LMCMA_STAMP(1);
 
@@ -340,7 +344,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, 
 
     // success-rule count: wave 0 adds its lanes' shares
 #pragma unroll
-    for (int u = 0; u < 16; ++u) psr_lane += (wl + 64 * u < a.n_psr_parts) ? pp[u] : 0u;
+    for (int u = 0; u < 16; ++u) psr_lane += (!a.scalars_in_rows && wl + 64 * u < a.n_psr_parts) ? pp[u] : 0u;
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) psr_lane += __shfl_xor(psr_lane, sft, 64);
 
@@ -397,7 +401,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, 
             s_ljp[pos] = lj_old;
         }
     }
-    row_sums_to_lds_t<true>(a.partials, a.n_partials, N, T, s_red, first_rows);
+    row_sums_to_lds_t<true>(a.partials, a.n_partials, N, a.partial_stride, T, s_red, first_rows);
     __syncthreads();
     LMCMA_STAMP(2);
     // L/:316-329: new mean, evolution path

@@ -7,11 +7,12 @@ global candidate index, so a candidate's row does not depend on G.  Per generati
 
   1. phase_local   sample + score the own candidates           (no communication)
   2. all-gather    the own costs -> every rank holds all lambda costs
-  3. phase_rank    every rank ranks all costs (identical result) and sums the
-                   weighted rows of the elites it owns          -> one N-vector
-  4. all-gather    the per-rank elite partial sums (G x N doubles)
-  5. phase_update  every rank adds the G partial sums in rank order and runs the
-                   LM-CMA update; the replicated state stays bit-identical
+  3. phase_rank    every rank finds the ranks of its own candidates among all costs
+                   and sums the weighted rows of the elites it owns; with its share
+                   of the success-rule count and the lowest cost -> one row of N + 2
+  4. all-gather    the per-rank rows (G x (N + 2) doubles)
+  5. phase_update  every rank adds the G rows in rank order and runs the LM-CMA
+                   update; the replicated state stays bit-identical
 
 The elite exchange moves each rank's weighted elite sum rather than the elite
 rows themselves: mu = lambda/2 (reference lmcma.cpp:136), so "the rows of the
@@ -49,6 +50,7 @@ class HipShard:
         self.partial_local = alias_tensor(ctx, hipmod.BUF_PARTIAL_LOCAL, torch.float64, device)
         self.partial_all = alias_tensor(ctx, hipmod.BUF_PARTIAL_ALL, torch.float64, device)
         self.N = ctx.N
+        self.partial_len = self.partial_local.numel()  # N + 2: elite sum, success-rule count, lowest cost
 
     def phase_local(self):
         self.ctx.phase_local()
@@ -96,5 +98,5 @@ def sharded_generation(shard, group=None):
     # cost_local is the rank's own block inside cost_all, so this is an in-place all-gather
     _all_gather(shard.cost_all, shard.cost_local, group)
     shard.phase_rank()
-    _all_gather(shard.partial_all[: world * shard.N], shard.partial_local, group)
+    _all_gather(shard.partial_all[: world * shard.partial_len], shard.partial_local, group)
     shard.phase_update(world)

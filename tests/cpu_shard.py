@@ -1,8 +1,10 @@
 """CPU stand-in for one rank's shard, used only by the gloo tests of the sharded
 generation loop (lmcma_path_planner_amd/dist.py).  It mirrors the semantics of the
 device phases with the oracle's fp64 functions: Philox rows by global candidate
-index, fp32-rounded rows and costs, stable ranking of all costs, rank-weighted
-partial sums of the own elites, replicated update."""
+index, fp32-rounded rows and costs, the local costs exchanged in ascending order,
+global ranks of the own candidates by merging the ranks' sorted lists (ties by rank
+order, i.e. by candidate index), rank-weighted partial sums of the own elites,
+replicated update."""
 import numpy as np
 import torch
 
@@ -19,8 +21,10 @@ class CpuShard:
                                       sigma=prob.sigma0, seed=seed, z_source=pyoracle.Z_GIVEN)
         self.cost_all = torch.zeros(lam_total, dtype=torch.float32)
         self.cost_local = self.cost_all[first:first + nloc]          # a view: in-place all-gather
-        self.partial_local = torch.zeros(prob.N, dtype=torch.float64)
-        self.partial_all = torch.zeros(max_partials * prob.N, dtype=torch.float64)
+        # a row is the elite sum plus two scalars (success-rule count, lowest cost), like the device's
+        self.partial_len = prob.N + 2
+        self.partial_local = torch.zeros(self.partial_len, dtype=torch.float64)
+        self.partial_all = torch.zeros(max_partials * self.partial_len, dtype=torch.float64)
         self.rows = None
         self.order = None
 
@@ -32,24 +36,30 @@ class CpuShard:
         self.o.sample_given(Z)
         self.rows = self.o.arx[self.first:self.first + self.nloc].astype(np.float32)
         cost, _ = self.co.cost_rows_f32(self.rows)
-        self.cost_local.copy_(torch.from_numpy(cost.astype(np.float32)))
+        self.cost_raw = np.where(np.isnan(cost), np.inf, cost).astype(np.float32)
+        self.local_order = np.argsort(self.cost_raw.astype(np.float64), kind="stable")
+        self.cost_local.copy_(torch.from_numpy(self.cost_raw[self.local_order]))   # ascending
 
     def phase_rank(self):
-        costs = self.cost_all.numpy().astype(np.float64)
-        self.order = np.argsort(costs, kind="stable")
+        lists = self.cost_all.numpy().reshape(-1, self.nloc)
+        me = self.first // self.nloc
+        mine = lists[me]
+        rank = np.arange(self.nloc)
+        for g in range(lists.shape[0]):
+            if g != me:
+                rank = rank + np.searchsorted(lists[g], mine, side="right" if g < me else "left")
         w = self.o.weights
         acc = np.zeros(self.N)
-        for r in range(self.o.mu):
-            local = self.order[r] - self.first
-            if 0 <= local < self.nloc:
-                acc += w[r] * self.rows[local].astype(np.float64)
-        self.partial_local.copy_(torch.from_numpy(acc))
+        for p in np.argsort(rank):                      # own elites in rank order
+            if rank[p] < self.o.mu:
+                acc += w[rank[p]] * self.rows[self.local_order[p]].astype(np.float64)
+        self.partial_local[: self.N].copy_(torch.from_numpy(acc))
 
     def phase_update(self, n_partials):
         if n_partials == 0:
-            xnew = self.partial_local.numpy().copy()
+            xnew = self.partial_local.numpy()[: self.N].copy()
         else:
-            parts = self.partial_all.numpy()[: n_partials * self.N].reshape(n_partials, self.N)
+            parts = self.partial_all.numpy()[: n_partials * self.partial_len].reshape(n_partials, self.partial_len)[:, : self.N]
             xnew = np.zeros(self.N)
             for p in range(n_partials):
                 xnew += parts[p]

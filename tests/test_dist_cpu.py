@@ -60,8 +60,11 @@ def test_sharded_generation_matches_unsharded(world, tmp_path):
         np.testing.assert_array_equal(r["xmean"], ranks[0]["xmean"])
         np.testing.assert_array_equal(r["v"], ranks[0]["v"])
         assert float(r["sigma"]) == float(ranks[0]["sigma"])
-        # the gathered costs are the unsharded run's costs exactly (rows do not depend on the sharding)
-        np.testing.assert_array_equal(r["cost_all"], single["cost_all"])
+        # the gathered costs (each rank's block in ascending order) are the unsharded run's costs
+        # exactly: rows do not depend on the sharding
+        np.testing.assert_array_equal(np.sort(r["cost_all"]), np.sort(single["cost_all"]))
+        nloc = LAM // world
+        assert all(np.all(np.diff(r["cost_all"][g * nloc:(g + 1) * nloc]) >= 0) for g in range(world))
         # the mean differs from the unsharded run only by the grouping of the fp64 partial sums
         np.testing.assert_allclose(r["xmean"], single["xmean"], rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(float(r["sigma"]), float(single["sigma"]), rtol=1e-12)

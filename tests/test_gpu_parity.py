@@ -481,8 +481,9 @@ def test_two_shards_on_one_gpu_match_the_unsharded_population(hip):
         for c in parts:
             c.synchronize()
         for s in shards:
-            s.partial_all[:N].copy_(shards[0].partial_local)
-            s.partial_all[N:2 * N].copy_(shards[1].partial_local)
+            L = s.partial_len                      # N + 2: elite sum, success-rule count, lowest cost
+            s.partial_all[:L].copy_(shards[0].partial_local)
+            s.partial_all[L:2 * L].copy_(shards[1].partial_local)
         torch.cuda.synchronize()
         for c in parts:
             c.phase_update(2)
