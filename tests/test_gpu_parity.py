@@ -499,6 +499,72 @@ def test_two_shards_on_one_gpu_match_the_unsharded_population(hip):
         c.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,mode", [(4, "ties"), (8, "random"), (3, "random")])
+def test_merged_ranks_of_shards_equal_the_stable_sort_of_the_whole_population(hip, G, mode):
+    """G shards on one GPU; after the hand-made exchange of the sorted local costs every
+    shard's entries of the global permutation and sorted list must be those of a stable
+    sort of all costs in candidate order.  "ties": degenerate bounds make every candidate
+    the same path, so all costs are equal and the order must be the candidate order, across
+    shards too."""
+    import torch
+    from lmcma_path_planner_amd import dist as shard_mod
+    from lmcma_path_planner_amd import grids
+    prob = grids.benchmark_problem(2)
+    nloc = 256
+    lam = G * nloc
+    dev = torch.device("cuda", 0)
+    lo, hi = (prob.x0, prob.x0) if mode == "ties" else (prob.lo, prob.hi)
+    ctxs = []
+    for g in range(G):
+        c = hip.HipContext(prob.N, lam, prob.m, dims=2, waypoints=prob.W, lambda_local=nloc, first_candidate=g * nloc,
+                           start=prob.start, goal=prob.goal, seed=5)
+        c.set_grid(prob.occ)
+        c.set_bounds(lo, hi)
+        c.opt_init(prob.x0, prob.sigma0)
+        ctxs.append(c)
+    shards = [shard_mod.HipShard(c, dev) for c in ctxs]
+    for gen in range(3):
+        for c in ctxs:
+            c.phase_local()
+        for c in ctxs:
+            c.synchronize()
+        raw = np.concatenate([c.costs() for c in ctxs]).astype(np.float32)
+        for s in shards:                                   # the "all-gather"
+            for g, src in enumerate(shards):
+                s.cost_all[g * nloc:(g + 1) * nloc].copy_(src.cost_local)
+        torch.cuda.synchronize()
+        for c in ctxs:
+            c.phase_rank()
+        for c in ctxs:
+            c.synchronize()
+        order = _reference_order(raw)
+        want_rank = np.empty(lam, dtype=np.int64)
+        want_rank[order] = np.arange(lam)
+        for g, c in enumerate(ctxs):
+            perm = shard_mod.alias_tensor(c, hip.BUF_PERM, torch.int32, dev).cpu().numpy()
+            sc = shard_mod.alias_tensor(c, hip.BUF_SORTED_COST, torch.float32, dev).cpu().numpy()
+            own = np.arange(g * nloc, (g + 1) * nloc)
+            np.testing.assert_array_equal(perm[want_rank[own]], own)          # each own candidate sits at its rank
+            np.testing.assert_array_equal(sc[want_rank[own]], raw[own])
+        if mode == "ties":
+            assert np.all(raw == raw[0])
+        L = shards[0].partial_len
+        for s in shards:
+            for g, src in enumerate(shards):
+                s.partial_all[g * L:(g + 1) * L].copy_(src.partial_local)
+        torch.cuda.synchronize()
+        for c in ctxs:
+            c.phase_update(G)
+    states = [c.opt_get() for c in ctxs]
+    for st in states[1:]:
+        np.testing.assert_array_equal(st["xmean"], states[0]["xmean"])       # replicas stay bit-identical
+        assert st["sigma"] == states[0]["sigma"] and st["best_f"] == states[0]["best_f"]
+    assert states[0]["best_f"] == float(raw.min()) or states[0]["best_f"] <= float(raw.min())
+    for c in ctxs:
+        c.close()
+
+
 def test_cpp_examples_against_the_drop_in_header():
     """examples/*.cpp are written against include/lmcma.hpp like a caller of the reference's
     header; the binaries are built on the CPU box by __graft_entry__.build()."""
