@@ -107,6 +107,16 @@ int lmcma_hip_set_state(lmcma_hip_ctx *ctx, const double *xmean, double sigma,
                         const double *V, const double *PC, const double *nj,
                         int k, double M);
 
+/* The `covariance` argument of the constructor (L/lmcma.hpp:131-133) after
+ * cholesky() (L/lmcma.cpp:165-169, 844-855): L[c*N + r] = Lm(r, c), the lower
+ * factor column-major.  With it every candidate's Philox normals become
+ * z <- Lm z before the low-rank transform, as sampleStandardNormal + applyCovL
+ * do (L/lmcma.cpp:212-218, 857-864); the product runs in fp32 on the matrix
+ * cores.  NULL returns to the identity.  z_source PHILOX only: a caller that
+ * draws its own normals (z_source HOST) applies the factor itself.  While a
+ * factor is set the generation samples and scores in two launches.            */
+int lmcma_hip_set_cov_factor(lmcma_hip_ctx *ctx, const double *L);
+
 /* LMCMA::sample (L/lmcma.cpp:301-311) for this context's candidates.
  * z_host: [lambda_local][N] standard normals drawn by the caller (z_source
  * HOST, e.g. from random_Gauss, L/lmcma.cpp:63-82, with applyCovL already
@@ -227,6 +237,9 @@ enum { LMCMA_K_SAMPLE = 0, LMCMA_K_COST = 1, LMCMA_K_SELECT = 2, LMCMA_K_RECOMBI
 int lmcma_hip_timing_enable(lmcma_hip_ctx *ctx, int on);
 int lmcma_hip_timing_get(lmcma_hip_ctx *ctx, double ms[LMCMA_K_COUNT],
                          int64_t launches[LMCMA_K_COUNT]);
+/* average reading of `pairs` (1..4096) empty event brackets on the context's stream:
+ * the share of a bracketed launch's reading that is not the kernel itself.      */
+int lmcma_hip_timing_event_overhead(lmcma_hip_ctx *ctx, int pairs, double *ms_per_pair);
 
 #ifdef __cplusplus
 }

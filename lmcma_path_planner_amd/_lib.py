@@ -80,6 +80,7 @@ SIGNATURES = {
     "lmcma_hip_destroy": (_i, [_vp]),
     "lmcma_hip_set_grid": (_i, [_vp, _vp, _i, _i, _i, _i, ctypes.c_double]),
     "lmcma_hip_set_bounds": (_i, [_vp, c_double_p, c_double_p]),
+    "lmcma_hip_set_cov_factor": (_i, [_vp, c_double_p]),
     "lmcma_hip_set_state": (_i, [_vp, c_double_p, ctypes.c_double, c_double_p, c_double_p, c_double_p, _i,
                                  ctypes.c_double]),
     "lmcma_hip_sample": (_i, [_vp, ctypes.c_uint32, c_double_p]),
@@ -105,6 +106,7 @@ SIGNATURES = {
     "lmcma_hip_synchronize": (_i, [_vp]),
     "lmcma_hip_timing_enable": (_i, [_vp, _i]),
     "lmcma_hip_timing_get": (_i, [_vp, c_double_p, c_int64_p]),
+    "lmcma_hip_timing_event_overhead": (_i, [_vp, _i, c_double_p]),
     # lmcma_opt.h
     "lmcma_opt_last_error": (ctypes.c_char_p, []),
     "lmcma_opt_create": (_i, [c_double_p, c_double_p, c_double_p, c_double_p, _i, _i, ctypes.c_double, _i, _i,

@@ -121,6 +121,10 @@ struct lmcma_hip_ctx {
     float c_obs = 1.f, c_start = 0.f, c_goal = 0.f;
     bool grid_lds = false;
     bool fused = true;   // sample + score in one kernel on the device-resident path
+    // factor of a structured sampling covariance (device Philox normals only)
+    float *cov_L = nullptr;
+    CovFactor cov{};
+    bool have_cov = false;
 
     bool have_state = false, have_weights = false, opt_ready = false;
     bool sampled = false, costs_ready = false, selected = false;
@@ -254,8 +258,10 @@ CostParams cost_params(const lmcma_hip_ctx *c, const float *rows, int n_rows, fl
 int do_sample(lmcma_hip_ctx *c, const float *z)
 {
     Timed tm(c, LMCMA_K_SAMPLE);
+    // normals handed in by the caller already carry the factor (sampleStandardNormal applies it
+    // where it draws them, L/lmcma.cpp:212-218)
     HIP_TRY(launch_sample(c->stream, c->rows, z, c->xmean_f, c->V_f, c->B_f, c->lo_f, c->hi_f, c->sc,
-                          c->ld, c->nloc, (uint32_t)c->first, c->cfg.seed));
+                          c->ld, c->nloc, (uint32_t)c->first, c->cfg.seed, (c->have_cov && !z) ? &c->cov : nullptr));
     c->sampled = true;
     return LMCMA_HIP_OK;
 }
@@ -380,7 +386,7 @@ int do_update(lmcma_hip_ctx *c, const double *partials, int n_partials, bool row
 int one_generation(lmcma_hip_ctx *c)
 {
     int rc;
-    if (c->fused) {
+    if (c->fused && !c->have_cov) {
         if ((rc = do_generate(c)) != LMCMA_HIP_OK) return rc;
     } else {
         if ((rc = do_sample(c, nullptr)) != LMCMA_HIP_OK) return rc;
@@ -546,7 +552,7 @@ int lmcma_hip_destroy(lmcma_hip_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graph(c);
     for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    void *bufs[] = {c->arena, c->zbuf, c->scratch_rows, c->scratch_cost, c->scratch_terms, c->grid};
+    void *bufs[] = {c->arena, c->zbuf, c->cov_L, c->scratch_rows, c->scratch_cost, c->scratch_terms, c->grid};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -673,6 +679,40 @@ int lmcma_hip_set_state(lmcma_hip_ctx *c, const double *xmean, double sigma, con
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_state = true;
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_set_cov_factor(lmcma_hip_ctx *c, const double *L)
+{
+    CTX_TRY(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);  // a captured generation holds the kernels of the other sampling mode
+    if (!L) {
+        c->have_cov = false;
+        return LMCMA_HIP_OK;
+    }
+    if (c->cfg.z_source != LMCMA_Z_PHILOX)
+        return fail(LMCMA_HIP_ERR_STATE, "set_cov_factor: with z_source HOST the caller applies the factor to its normals");
+    const int N = c->N, nt = (std::max(N, c->ld) + 15) / 16, np = 16 * nt;
+    if (nt > 32) return fail(LMCMA_HIP_ERR_UNSUPPORTED, "set_cov_factor: N up to 512");
+    std::vector<float> lf((size_t)np * np, 0.f);
+    CovFactor f{};
+    f.ld = np;
+    f.ntiles = nt;
+    for (int t = 0; t < nt; ++t) f.kblocks[t] = 1;
+    for (int col = 0; col < N; ++col)
+        for (int row = 0; row < N; ++row) {
+            const double v = L[(size_t)col * N + row];  // column-major, as cholesky() leaves it (L/lmcma.cpp:846-853)
+            if (!std::isfinite(v)) return fail(LMCMA_HIP_ERR_ARG, "set_cov_factor: the factor holds a value that is not finite");
+            const float fv = (float)v;
+            lf[(size_t)row * np + col] = fv;
+            if (fv != 0.f && f.kblocks[row / 16] < col / 16 + 1) f.kblocks[row / 16] = (uint8_t)(col / 16 + 1);
+        }
+    if (!c->cov_L) HIP_TRY(dalloc(&c->cov_L, (size_t)np * np));
+    HIP_TRY(hipMemcpy(c->cov_L, lf.data(), lf.size() * sizeof(float), hipMemcpyHostToDevice));
+    f.L = c->cov_L;
+    c->cov = f;
+    c->have_cov = true;
     return LMCMA_HIP_OK;
 }
 
@@ -959,7 +999,7 @@ int lmcma_hip_phase_local(lmcma_hip_ctx *c)
     if (!c->grid) return fail(LMCMA_HIP_ERR_STATE, "set_grid must come first");
     if (c->cfg.z_source != LMCMA_Z_PHILOX) return fail(LMCMA_HIP_ERR_STATE, "phases need z_source PHILOX");
     int rc;
-    if (c->fused) {
+    if (c->fused && !c->have_cov) {
         rc = do_generate(c);
     } else {
         rc = do_sample(c, nullptr);
@@ -1129,6 +1169,39 @@ int lmcma_hip_timing_get(lmcma_hip_ctx *c, double ms[LMCMA_K_COUNT], int64_t lau
         if (launches) launches[i] = c->t_n[i];
     }
     return LMCMA_HIP_OK;
+}
+
+// What a pair of event records with nothing between them measures on this stream: the
+// part of a bracketed kernel's reading that is not the kernel.
+int lmcma_hip_timing_event_overhead(lmcma_hip_ctx *c, int pairs, double *ms_per_pair)
+{
+    CTX_TRY(c);
+    if (pairs < 1 || pairs > 4096 || !ms_per_pair) return fail(LMCMA_HIP_ERR_ARG, "timing_event_overhead: pairs in 1..4096");
+    std::vector<EventPair> ev((size_t)pairs);
+    int rc = LMCMA_HIP_OK;
+    size_t made = 0;
+    for (; made < ev.size(); ++made) {
+        if (hipEventCreate(&ev[made].a) != hipSuccess) break;
+        if (hipEventCreate(&ev[made].b) != hipSuccess) { (void)hipEventDestroy(ev[made].a); break; }
+    }
+    if (made < ev.size()) rc = fail(LMCMA_HIP_ERR_RUNTIME, "timing_event_overhead: hipEventCreate failed");
+    double total = 0.0;
+    if (rc == LMCMA_HIP_OK) {
+        for (auto &p : ev) {
+            (void)hipEventRecord(p.a, c->stream);
+            (void)hipEventRecord(p.b, c->stream);
+        }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(LMCMA_HIP_ERR_RUNTIME, "timing_event_overhead: synchronize failed");
+        for (auto &p : ev) {
+            float ms = 0.f;
+            if (rc == LMCMA_HIP_OK && hipEventElapsedTime(&ms, p.a, p.b) != hipSuccess)
+                rc = fail(LMCMA_HIP_ERR_RUNTIME, "timing_event_overhead: hipEventElapsedTime failed");
+            total += ms;
+        }
+    }
+    for (size_t i = 0; i < made; ++i) { (void)hipEventDestroy(ev[i].a); (void)hipEventDestroy(ev[i].b); }
+    if (rc == LMCMA_HIP_OK) *ms_per_pair = total / pairs;
+    return rc;
 }
 
 }  // extern "C"

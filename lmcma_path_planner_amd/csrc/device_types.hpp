@@ -61,10 +61,21 @@ struct GenParams {
 // ---- launchers (each in the .hip file that defines its kernels) -------------
 hipError_t launch_generate(hipStream_t s, const GenParams &g, int dims, bool lds_grid);
 
+// Lower-triangular factor of a structured sampling covariance (applyCovL, L/lmcma.cpp:857-864):
+// z <- L z before the low-rank transform.  L is row-major fp32, (16 ntiles) x ld with
+// ld >= 16 ntiles, zero outside the N x N block; kblocks[t] = 16-wide column blocks of rows
+// 16 t .. 16 t + 15 that hold a non-zero (t + 1 for a full lower triangle).
+struct CovFactor {
+    const float *L;
+    int ld, ntiles;
+    uint8_t kblocks[32];
+};
+
+// cov: null for the identity
 hipError_t launch_sample(hipStream_t s, float *rows, const float *zbuf, const float *xmean,
                          const float *V, const float *B, const float *lo, const float *hi,
                          const SampleScalars *sc, int ld, int n_local, uint32_t first_candidate,
-                         uint64_t seed);
+                         uint64_t seed, const CovFactor *cov);
 
 // lds_grid: stage a bit grid in LDS when it fits
 hipError_t launch_cost(hipStream_t s, const CostParams &p, int dims, bool lds_grid);

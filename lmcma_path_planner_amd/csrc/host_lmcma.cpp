@@ -405,6 +405,8 @@ void LMCMA::init(int N)
     }
     d.hip(lmcma_hip_create(&cfg, &d.ctx), "lmcma_hip_create");
     if (d.loBounds || d.hiBounds) d.hip(lmcma_hip_set_bounds(d.ctx, d.loBounds, d.hiBounds), "lmcma_hip_set_bounds");
+    // normals drawn on the device get the factor there; host-drawn ones in sample()
+    if (d.philox && !d.Lchol.empty()) d.hip(lmcma_hip_set_cov_factor(d.ctx, d.Lchol.data()), "lmcma_hip_set_cov_factor");
     if (d.haveProblem)
         d.hip(lmcma_hip_set_grid(d.ctx, d.problem.cells, d.problem.nx, d.problem.ny, d.problem.nz,
                                  d.problem.cell_type, d.problem.c_obs),

@@ -12,14 +12,91 @@
 // bytes per step and the four groups of a wave64 share the same V/B cache lines.
 // The k dot products are reduced over the 16 lanes with an xor butterfly, which
 // leaves bit-identical sums in every lane of the group.
+//
+// Structured sampling (CMABase::sampleStandardNormal with a Cholesky factor,
+// lmcma.cpp:212-218, applyCovL :857-864): z <- L z before A is applied.  Over the 16
+// candidates of a workgroup that is the one dense product of the path, Z (16 x N) =
+// Z0 (16 x N) L^T, and it runs on the matrix cores: the workgroup leaves its Philox
+// normals in LDS, every wave takes output tiles of 16 coordinates and walks the 16-wide
+// blocks of L's rows with v_mfma_f32_16x16x4_f32 (L is lower triangular, so tile t needs
+// only its first t + 1 blocks), and the products go back through LDS into the lane layout
+// of the rest of the kernel.
 #include "device_funcs.hpp"
 
 namespace lmcma {
 
 namespace {
 
-// J = float4 chunks per lane; the row stride ld (a multiple of 4) must be <= 64 J.
+typedef float mfma_f32x4 __attribute__((ext_vector_type(4)));
+
+// z <- L z for the 16 candidates of the workgroup.  z holds the candidates' normals in
+// the lane layout of k_sample (zero beyond the row); s_z is [16][16 ntiles + 4] floats.
 template <int J>
+__device__ __forceinline__ void apply_factor(float4 (&z)[J], const CovFactor &f, float *s_z)
+{
+    const int tid = threadIdx.x, lane16 = tid & 15, grp = tid >> 4;
+    const int wl = tid & 63, wave = tid >> 6;
+    const int np = 16 * f.ntiles, ldp = np + 4;  // the pad spreads the 16 rows over the banks
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int col = 4 * (j * 16 + lane16);
+        if (col < np) *reinterpret_cast<float4 *>(s_z + grp * ldp + col) = z[j];
+    }
+    __syncthreads();
+    // this wave's tiles: 4 i + wave, then 4 i + 3 - wave, alternating, so that every wave
+    // gets the same share of the triangle
+    const int row = wl & 15, kq = 4 * (wl >> 4);
+    mfma_f32x4 acc[J];
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        acc[i] = mfma_f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nt = 4 * i + ((i & 1) ? 3 - wave : wave);
+        if (nt < f.ntiles) {
+            const float *a_src = s_z + row * ldp + kq;
+            const float *b_src = f.L + (size_t)(16 * nt + row) * f.ld + kq;
+            const int nkb = f.kblocks[nt];
+            for (int kb0 = 0; kb0 < nkb; kb0 += 4) {
+                // four blocks per step: all eight loads first, then the sixteen products
+                float4 a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kb = kb0 + u < nkb ? kb0 + u : nkb - 1;
+                    a[u] = *reinterpret_cast<const float4 *>(a_src + 16 * kb);
+                    b[u] = *reinterpret_cast<const float4 *>(b_src + 16 * kb);
+                    if (kb0 + u >= nkb) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    // lane (row, q) feeds element k = 16 kb + 4 q + s of its row in step s: the
+                    // four steps together cover the 16 k of the block
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();  // every wave has read the normals
+    // element r of a lane's result is candidate 4 (lane / 16) + r, coordinate 16 nt + lane % 16
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        const int nt = 4 * i + ((i & 1) ? 3 - wave : wave);
+        if (nt < f.ntiles) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_z[(kq + r) * ldp + 16 * nt + row] = acc[i][r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int col = 4 * (j * 16 + lane16);
+        if (col < np) z[j] = *reinterpret_cast<const float4 *>(s_z + grp * ldp + col);
+    }
+}
+
+// J = float4 chunks per lane; the row stride ld (a multiple of 4) must be <= 64 J.
+template <int J, bool COV>
 __global__ __launch_bounds__(256) void k_sample(float *__restrict__ rows,
                                                 const float *__restrict__ zbuf,
                                                 const float *__restrict__ xmean,
@@ -29,8 +106,9 @@ __global__ __launch_bounds__(256) void k_sample(float *__restrict__ rows,
                                                 const float *__restrict__ hi,
                                                 const SampleScalars *__restrict__ sc, int ld,
                                                 int n_local, uint32_t first_candidate,
-                                                uint32_t key0, uint32_t key1)
+                                                uint32_t key0, uint32_t key1, const CovFactor cov)
 {
+    extern __shared__ __attribute__((aligned(16))) float s_cov[];
     const int lane = threadIdx.x & 15;
     const int cand = blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool live = cand < n_local;
@@ -54,8 +132,10 @@ __global__ __launch_bounds__(256) void k_sample(float *__restrict__ rows,
         } else {
             z[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        acc[j] = make_float4(mk * z[j].x, mk * z[j].y, mk * z[j].z, mk * z[j].w);
     }
+    if (COV) apply_factor<J>(z, cov, s_cov);
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[j] = make_float4(mk * z[j].x, mk * z[j].y, mk * z[j].z, mk * z[j].w);
 
     for (int t = 0; t < k; ++t) {
         const float4 *v = reinterpret_cast<const float4 *>(V + (size_t)t * ld);
@@ -111,17 +191,30 @@ __global__ __launch_bounds__(256) void k_sample(float *__restrict__ rows,
 hipError_t launch_sample(hipStream_t s, float *rows, const float *zbuf, const float *xmean,
                          const float *V, const float *B, const float *lo, const float *hi,
                          const SampleScalars *sc, int ld, int n_local, uint32_t first_candidate,
-                         uint64_t seed)
+                         uint64_t seed, const CovFactor *cov)
 {
     if (n_local <= 0) return hipSuccess;
     if (ld <= 0 || (ld & 3) || ld > 512) return hipErrorInvalidValue;
     const dim3 grid((n_local + 15) / 16), block(256);
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const int J = (ld + 63) / 64;
+    CovFactor f{};
+    size_t lds = 0;
+    if (cov) {
+        f = *cov;
+        // the tiles cover the row, and every wave has room for its share of them
+        if (!f.L || f.ntiles < 1 || 16 * f.ntiles < ld || f.ntiles > 4 * J || f.ld < 16 * f.ntiles || (f.ld & 3))
+            return hipErrorInvalidValue;
+        lds = (size_t)16 * (16 * f.ntiles + 4) * sizeof(float);  // <= 33 KiB
+    }
 #define LMCMA_SAMPLE_CASE(JJ)                                                                  \
     case JJ:                                                                                   \
-        hipLaunchKernelGGL(k_sample<JJ>, grid, block, 0, s, rows, zbuf, xmean, V, B, lo, hi, sc, \
-                           ld, n_local, first_candidate, k0, k1);                              \
+        if (cov)                                                                               \
+            hipLaunchKernelGGL((k_sample<JJ, true>), grid, block, lds, s, rows, zbuf, xmean, V, B, lo, hi, sc, \
+                               ld, n_local, first_candidate, k0, k1, f);                       \
+        else                                                                                   \
+            hipLaunchKernelGGL((k_sample<JJ, false>), grid, block, 0, s, rows, zbuf, xmean, V, B, lo, hi, sc, \
+                               ld, n_local, first_candidate, k0, k1, f);                       \
         break;
     switch (J) {
         LMCMA_SAMPLE_CASE(1)

@@ -79,14 +79,19 @@ __global__ __launch_bounds__(1024) void k_recombine_final(const double *__restri
 }
 
 // ---- update, stand-alone ------------------------------------------------------------
-// TB threads do the vector work; the launch adds one wave for the step-size rule when the
-// workgroup has room for it
+// TB threads do the vector work.  The workgroup is larger when there is room: 512 threads
+// for TB = 256 (two waves per SIMD keep the whole register file per lane), all of which
+// read the partial rows and the first extra wave evaluates the step-size rule.  A ninth
+// wave would cut the registers per lane to a third of the file, and the kernel spills.
+constexpr int update_block_threads(int TB) { return TB == 256 ? 512 : TB; }
+constexpr int update_row_threads(int TB) { return TB == 256 ? 512 : TB; }
+
 template <int TB, int EMAX, bool V_LDS>
-__global__ __launch_bounds__(TB < 1024 ? TB + 64 : 1024) void k_update(const UpdateArgs a)
+__global__ __launch_bounds__(update_block_threads(TB)) void k_update(const UpdateArgs a)
 {
     // all LDS in one dynamic array of doubles
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-    update_body<EMAX, V_LDS>(a, s_dyn, TB);
+    update_body<EMAX, V_LDS>(a, s_dyn, TB, update_row_threads(TB));
 }
 
 }  // namespace
@@ -112,10 +117,11 @@ static int threads_for_vectors(int m)
 
 static bool update_fits_lds(int N, int m)
 {
-    return update_lds_doubles(N, m, threads_for_vectors(m), true) * sizeof(double) <= 150 * 1024;
+    return update_lds_doubles(N, m, update_row_threads(threads_for_vectors(m)), true) * sizeof(double) <= 150 * 1024;
 }
 
-int update_threads(int N, int m) { return update_fits_lds(N, m) ? threads_for_vectors(m) : 1024; }
+// threads that add the partial rows in the update (the order of that sum depends on it)
+int update_threads(int N, int m) { return update_fits_lds(N, m) ? update_row_threads(threads_for_vectors(m)) : 1024; }
 
 int recombine_num_blocks(int mu)
 {
@@ -148,7 +154,7 @@ hipError_t launch_recombine_final(hipStream_t s, const double *block_partials, i
 template <int TB, int EMAX, bool V_LDS>
 static hipError_t launch_update_t(hipStream_t s, const UpdateArgs &a)
 {
-    const size_t lds = update_lds_doubles(a.N, a.m, TB, V_LDS) * sizeof(double);
+    const size_t lds = update_lds_doubles(a.N, a.m, update_row_threads(TB), V_LDS) * sizeof(double);
     static size_t configured = 48 * 1024;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_update<TB, EMAX, V_LDS>),
@@ -156,7 +162,7 @@ static hipError_t launch_update_t(hipStream_t s, const UpdateArgs &a)
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL((k_update<TB, EMAX, V_LDS>), dim3(1), dim3(TB < 1024 ? TB + 64 : 1024), lds, s, a);
+    hipLaunchKernelGGL((k_update<TB, EMAX, V_LDS>), dim3(1), dim3(update_block_threads(TB)), lds, s, a);
     return hipGetLastError();
 }
 
@@ -164,7 +170,7 @@ hipError_t launch_update(hipStream_t s, const UpdateArgs &a)
 {
     if (a.m < 1 || a.m > LMCMA_HIP_MAX_VECTORS || a.N < 1 || a.N > 512 || a.n_partials < 1)
         return hipErrorInvalidValue;
-    const int threads = update_threads(a.N, a.m);
+    const int threads = threads_for_vectors(a.m);
     const int emax = (a.N + 15) / 16;
     if (!update_fits_lds(a.N, a.m)) return launch_update_t<1024, 32, false>(s, a);  // m > 32 and N > 256
 #define LMCMA_UPD(TB)                                          \

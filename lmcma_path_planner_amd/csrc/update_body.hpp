@@ -199,16 +199,19 @@ static __device__ unsigned long long g_update_stamps[16];
 #define LMCMA_STAMP(i)
 #endif
 
-// LDS doubles the update needs for (N, m) with T threads
-__host__ __device__ inline size_t update_lds_doubles(int N, int m, int T, bool v_lds)
+// LDS doubles the update needs for (N, m) when TR threads read the partial rows
+__host__ __device__ inline size_t update_lds_doubles(int N, int m, int TR, bool v_lds)
 {
     const size_t np = N <= 128 ? 128 : N <= 256 ? 256 : 512;  // 16 lanes x 8, 16 or 32 coordinates
-    return (v_lds ? (size_t)m * np : 0) + np + row_sum_lds_doubles(N, T) + 2 * LMCMA_HIP_MAX_VECTORS;
+    return (v_lds ? (size_t)m * np : 0) + np + row_sum_lds_doubles(N, TR) + 2 * LMCMA_HIP_MAX_VECTORS;
 }
 
 // T >= 16 m threads (T a multiple of 64) of one workgroup do the vector work; when the
-// workgroup has one more wave, that wave evaluates the step-size rule beside them (its
-// divisions and exponential would otherwise hold up a wave the others wait for).  The 16 lanes
+// workgroup has more waves, the first of them evaluates the step-size rule beside the
+// workers (its divisions and exponential would otherwise hold up a wave the others wait
+// for).  The first TR threads of the workgroup (TR >= T) read the partial rows of the new
+// mean: a single workgroup reads freshly written rows faster the more loads it has in
+// flight, so the extra waves exist mainly for that.  The 16 lanes
 // of group g own SLOT g of the direction store (EMAX >= N / 16 coordinates per lane in
 // registers), so every load of the kernel can be issued at its start: nothing waits for
 // the slot tables.  V_LDS: finished vectors are published through LDS (m * N doubles,
@@ -216,7 +219,7 @@ __host__ __device__ inline size_t update_lds_doubles(int N, int m, int T, bool v
 // memory.  Global stores are kept out of the loop (a workgroup barrier waits for
 // outstanding stores) and issued at the end.
 template <int EMAX, bool V_LDS>
-__device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, int T)
+__device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, int T, int TR)
 {
     constexpr bool KEEP_PC = EMAX <= 8;  // evolution paths stay in registers when they fit
     const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
@@ -236,7 +239,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, 
     double *s_v = s_dyn;                                  // [m][NP] when V_LDS, by position; zero beyond N
     double *s_pc = s_dyn + (V_LDS ? (size_t)m * NP : 0);  // [NP] new evolution path, zero beyond N
     double *s_red = s_pc + NP;                            // [rg][N] partial column sums
-    double *s_nv = s_red + row_sum_lds_doubles(N, T);               // [64], |v_i|^2 by position i
+    double *s_nv = s_red + row_sum_lds_doubles(N, TR);              // [64], |v_i|^2 by position i
     double *s_ljp = s_nv + LMCMA_HIP_MAX_VECTORS;         // [64], lj of the untouched vectors by position
 
     LMCMA_STAMP(0);
@@ -288,16 +291,20 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, 
     }
     double vold[EMAX], pcq[EMAX];
 #pragma unroll
-    for (int e = 0; e < EMAX; ++e) {
-        const int n = e * 16 + lane;
-        const size_t at = (size_t)slot * N + (n < N ? n : N - 1);
-        pcq[e] = a.pc_arr[at];
-        vold[e] = a.v_arr[at];
+    for (int e = 0; e < EMAX; ++e) pcq[e] = vold[e] = 0.0;
+    if (worker) {
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const int n = e * 16 + lane;
+            const size_t at = (size_t)slot * N + (n < N ? n : N - 1);
+            pcq[e] = a.pc_arr[at];
+            vold[e] = a.v_arr[at];
+        }
     }
     // L/:316-329: the rank-ordered partial sums of the new mean; the slot bookkeeping and the
     // step-size rule below run while these loads are in flight
     RowSumBatch first_rows;
-    row_sums_begin(a.partials, a.n_partials, N, a.partial_stride, T, first_rows);
+    row_sums_begin(a.partials, a.n_partials, N, a.partial_stride, TR, first_rows);
     asm volatile("" ::: "memory");  // no load above is moved below this point
     LMCMA_STAMP(1);
 
@@ -401,7 +408,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, 
             s_ljp[pos] = lj_old;
         }
     }
-    row_sums_to_lds_t<true>(a.partials, a.n_partials, N, a.partial_stride, T, s_red, first_rows);
+    row_sums_to_lds_t<true>(a.partials, a.n_partials, N, a.partial_stride, TR, s_red, first_rows);
     __syncthreads();
     LMCMA_STAMP(2);
     // L/:316-329: new mean, evolution path
@@ -410,7 +417,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, 
     for (int q = 0; q < 2; ++q) {
         const int n = tid + q * T;
         if (worker && n < N) {
-            xnew[q] = row_sums_total(s_red, N, n, row_sum_groups(N, T));
+            xnew[q] = row_sums_total(s_red, N, n, row_sum_groups(N, TR));
             pcn[q] = (1 - cc) * pcold[q] + pc_gain * (xnew[q] - xold[q]) / sigma;
             s_pc[n] = pcn[q];
         }

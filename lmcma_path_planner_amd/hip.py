@@ -101,6 +101,15 @@ class HipContext:
         lo, hi = _f64(lo), _f64(hi)
         check_hip(self.lib.lmcma_hip_set_bounds(self._h, _dp(lo), _dp(hi)), "lmcma_hip_set_bounds")
 
+    def set_cov_factor(self, L):
+        """Lower Cholesky factor of the sampling covariance, column-major [N*N] as the
+        reference's cholesky() stores it (or an (N, N) array holding Lm transposed, which is
+        the same memory); None for the identity."""
+        L = _f64(L)
+        if L is not None and L.size != self.N * self.N:
+            raise ValueError("set_cov_factor: the factor has N * N entries")
+        check_hip(self.lib.lmcma_hip_set_cov_factor(self._h, _dp(L)), "lmcma_hip_set_cov_factor")
+
     def set_state(self, xmean, sigma, V=None, PC=None, nj=None, M=1.0):
         xmean, V, PC, nj = _f64(xmean), _f64(V), _f64(PC), _f64(nj)
         k = 0 if V is None else V.shape[0]
@@ -221,3 +230,10 @@ class HipContext:
         check_hip(self.lib.lmcma_hip_timing_get(self._h, _dp(ms), n.ctypes.data_as(c_int64_p)),
                   "lmcma_hip_timing_get")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(KERNEL_CLASSES)}
+
+    def timing_event_overhead(self, pairs=512):
+        """Milliseconds an empty event bracket reads on the context's stream."""
+        ms = ctypes.c_double(0.0)
+        check_hip(self.lib.lmcma_hip_timing_event_overhead(self._h, pairs, ctypes.byref(ms)),
+                  "lmcma_hip_timing_event_overhead")
+        return ms.value

@@ -93,6 +93,93 @@ def test_sample_with_philox_matches_oracle(hip, oracle):
     ctx.close()
 
 
+@pytest.mark.parametrize("N,dims,W,factor", [(128, 2, 64, "smooth"), (144, 3, 48, "smooth"), (6, 2, 3, "smooth"),
+                                               (33, 3, 11, "dense"), (288, 3, 96, "smooth"), (512, 2, 256, "band")])
+def test_sample_with_structured_covariance_matches_oracle(hip, oracle, N, dims, W, factor):
+    """z <- L z on the matrix cores (fp32) against applyCovL in fp64 on the same Philox normals.
+    Tolerance: 1e-5 of the largest |L z| (sums of up to N fp32 products), then the usual
+    2e-5 bound on the rows."""
+    lam, m, gens, seed, first, nloc = 96, 8, 11, 987654321, 16, 72
+    rng = np.random.default_rng(3)
+    if factor == "smooth":
+        L = oracle.cholesky(oracle.covariance(dims, W))           # column-major lower factor, as cholesky() leaves it
+    elif factor == "dense":
+        L = rng.normal(size=(N, N)) / np.sqrt(N)                   # not triangular: every block of every row counts
+    else:
+        Lm = np.tril(rng.normal(size=(N, N))) * (np.abs(np.subtract.outer(np.arange(N), np.arange(N))) < 40)
+        L = np.ascontiguousarray(Lm.T)                             # L[c*N + r] = Lm(r, c)
+    Lm = L.reshape(N, N).T
+    Z0 = np.stack([oracle.philox_normals(seed, gens, first + i, N) for i in range(nloc)])
+    Zc = Z0 @ Lm.T
+    np.testing.assert_allclose(oracle.apply_cov_l(L, Z0[0]), Zc[0], rtol=1e-12, atol=1e-12)
+    ctx = hip.HipContext(N, lam, m, lambda_local=nloc, first_candidate=first, z_source=hip.Z_PHILOX,
+                         cost_source=hip.COST_EXTERNAL, seed=seed)
+    ctx.set_cov_factor(L)
+    # k = 0, sigma = 1, xmean = 0: the rows are L z themselves
+    ctx.set_state(np.zeros(N), 1.0, None, None, None, 1.0)
+    ctx.sample(generation=gens)
+    assert np.max(np.abs(ctx.rows() - Zc)) <= 1e-5 * max(1.0, np.abs(Zc).max())
+    # with an evolved direction store on top
+    o = _evolved_oracle(oracle, N, lam, m, gens)
+    st = _state_of(o)
+    Zfull = np.zeros((lam, N))
+    Zfull[:nloc] = Zc
+    o.sample_given(Zfull)
+    want = o.arx[:nloc]
+    ctx.set_state(st["xmean"], st["sigma"], st["V"], st["PC"], st["nj"], st["M"])
+    ctx.sample(generation=gens)
+    scale = np.abs(st["xmean"]).max() + np.abs(want - st["xmean"]).max() + 1.0
+    assert np.max(np.abs(ctx.rows() - want)) <= 2e-5 * scale
+    # back to the identity
+    ctx.set_cov_factor(None)
+    ctx.set_state(np.zeros(N), 1.0, None, None, None, 1.0)
+    ctx.sample(generation=gens)
+    assert np.max(np.abs(ctx.rows() - Z0)) <= 4e-6
+    ctx.close()
+
+
+def test_device_generations_with_structured_covariance_follow_the_oracle(hip, oracle):
+    """The whole device loop (Philox normals, L z, sample, score, rank, update) with a factor
+    set, against the oracle driven with the device's own costs generation by generation."""
+    from lmcma_path_planner_amd import grids
+    prob = grids.benchmark_problem(1)
+    N, lam, m = prob.N, 64, 8
+    cov = oracle.covariance(2, prob.W)
+    L = oracle.cholesky(cov)
+    sigma0 = prob.sigma0 * 8.0
+    ctx = hip.HipContext(N, lam, m, dims=2, waypoints=prob.W, seed=42, start=prob.start, goal=prob.goal)
+    ctx.set_grid(prob.cells)
+    ctx.set_bounds(prob.lo, prob.hi)
+    ctx.set_cov_factor(L)
+    ctx.opt_init(prob.x0, sigma0)
+    o = oracle.OracleLMCMA(N, lam, m, initial=prob.x0, lo=prob.lo, hi=prob.hi, sigma=sigma0, cov=cov, seed=42,
+                           z_source=oracle.Z_PHILOX)
+    co = oracle.CostOracle(2, prob.W, prob.cells, prob.start, prob.goal)
+    for g in range(12):
+        ctx.phase_local()
+        rows = ctx.rows()
+        scale = np.abs(o.xmean).max() + np.abs(o.arx - o.xmean).max() + 1.0
+        assert np.max(np.abs(rows - o.arx)) <= 4e-5 * scale, g
+        want, _ = co.cost_rows_f32(rows.astype(np.float32))
+        got = ctx.costs()
+        assert np.max(np.abs(got - want) / np.maximum(1, np.abs(want))) <= 1e-5
+        ctx.phase_rank()
+        ctx.phase_update(0)
+        # the oracle continues from the device's rows and costs, so that rounding in the rows does not
+        # send the two runs down different rankings
+        o.set_arx(rows)
+        o.tell_all(got)
+        st = ctx.opt_get()
+        np.testing.assert_allclose(st["xmean"], o.xmean, rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(st["sigma"], o.sigma, rtol=1e-11)
+    # and the same generations from one graph launch sequence
+    ctx.opt_reset()
+    ctx.run(12)
+    st2 = ctx.opt_get()
+    np.testing.assert_array_equal(st2["xmean"], st["xmean"])
+    ctx.close()
+
+
 def _random_rows(rng, prob, count, spread):
     base = prob.x0 + rng.normal(scale=spread, size=(count, prob.N))
     return np.clip(base, prob.lo, prob.hi).astype(np.float32)
@@ -409,11 +496,14 @@ def test_lmcma_class_batched_step_with_host_update_and_structured_covariance(ora
         opt.close()
 
 
-def test_lmcma_class_device_update_mode(oracle):
-    from lmcma_path_planner_amd import LMCMA, grids
+@pytest.mark.parametrize("use_cov", [False, True])
+def test_lmcma_class_device_update_mode(oracle, use_cov):
+    from lmcma_path_planner_amd import LMCMA, grids, planner
     prob = grids.benchmark_problem(1)
     co = oracle.CostOracle(2, prob.W, prob.occ, prob.start, prob.goal)
-    opt = LMCMA(prob.x0, prob.lam, prob.lo, prob.hi, prob.sigma0, None, 42)
+    # the constructor's covariance argument reaches the device sampler as its Cholesky factor
+    cov = planner.covariance(2, prob.W) if use_cov else None
+    opt = LMCMA(prob.x0, prob.lam, prob.lo, prob.hi, prob.sigma0 * (8.0 if use_cov else 1.0), cov, 42)
     opt.setOptions(m=prob.m, philox=True, device_update=True)
     opt.setTrajectoryProblem(2, prob.W, prob.occ, prob.start, prob.goal)
     opt.init(prob.N)
