@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", type=int, default=2, help="benchmark configuration (2 = the headline one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--structured-covariance", action="store_true",
+                    help="sample with the smoothness covariance of the reference (z <- L z on the matrix cores); "
+                    "not the headline workload")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL) for real runs; gloo only to rehearse the "
                     "N > 1 code path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -123,7 +126,10 @@ def main():
                          device=local_rank, stream=stream)
     ctx.set_grid(prob.cells)
     ctx.set_bounds(prob.lo, prob.hi)
-    ctx.opt_init(prob.x0, prob.sigma0)
+    if args.structured_covariance:
+        from lmcma_path_planner_amd import planner
+        ctx.set_cov_factor(planner.cholesky(planner.covariance(prob.dims, prob.W)))
+    ctx.opt_init(prob.x0, prob.sigma0 * (8.0 if args.structured_covariance else 1.0))
 
     if world == 1:
         def run_steps(k):
@@ -200,7 +206,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": prob.name, "grid": "x".join(str(s) for s in prob.cells.shape),
+            "config": {"workload": prob.name + ("+structured-covariance" if args.structured_covariance else ""), "grid": "x".join(str(s) for s in prob.cells.shape),
                        "waypoints": prob.W, "n_params": prob.N, "lambda_per_gpu": lam_local,
                        "lambda_total": lam_total, "m": prob.m, "z_source": "philox4x32-10",
                        "update": "on device, fp64", "episode_generations": EPISODE, "exchange": "all-gather of sorted local costs + all-gather of elite partial sums (N+2 doubles per rank)"

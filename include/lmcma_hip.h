@@ -113,8 +113,7 @@ int lmcma_hip_set_state(lmcma_hip_ctx *ctx, const double *xmean, double sigma,
  * z <- Lm z before the low-rank transform, as sampleStandardNormal + applyCovL
  * do (L/lmcma.cpp:212-218, 857-864); the product runs in fp32 on the matrix
  * cores.  NULL returns to the identity.  z_source PHILOX only: a caller that
- * draws its own normals (z_source HOST) applies the factor itself.  While a
- * factor is set the generation samples and scores in two launches.            */
+ * draws its own normals (z_source HOST) applies the factor itself.             */
 int lmcma_hip_set_cov_factor(lmcma_hip_ctx *ctx, const double *L);
 
 /* LMCMA::sample (L/lmcma.cpp:301-311) for this context's candidates.

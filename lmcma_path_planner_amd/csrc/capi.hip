@@ -287,6 +287,7 @@ int do_generate(lmcma_hip_ctx *c)
     g.key0 = (uint32_t)c->cfg.seed;
     g.key1 = (uint32_t)(c->cfg.seed >> 32);
     g.cost = cost_params(c, c->rows, c->nloc, local_costs(c), c->terms);
+    if (c->have_cov) g.cov = c->cov;
     HIP_TRY(launch_generate(c->stream, g, c->D, c->grid_lds));
     c->sampled = true;
     return LMCMA_HIP_OK;
@@ -386,7 +387,7 @@ int do_update(lmcma_hip_ctx *c, const double *partials, int n_partials, bool row
 int one_generation(lmcma_hip_ctx *c)
 {
     int rc;
-    if (c->fused && !c->have_cov) {
+    if (c->fused) {
         if ((rc = do_generate(c)) != LMCMA_HIP_OK) return rc;
     } else {
         if ((rc = do_sample(c, nullptr)) != LMCMA_HIP_OK) return rc;
@@ -999,7 +1000,7 @@ int lmcma_hip_phase_local(lmcma_hip_ctx *c)
     if (!c->grid) return fail(LMCMA_HIP_ERR_STATE, "set_grid must come first");
     if (c->cfg.z_source != LMCMA_Z_PHILOX) return fail(LMCMA_HIP_ERR_STATE, "phases need z_source PHILOX");
     int rc;
-    if (c->fused && !c->have_cov) {
+    if (c->fused) {
         rc = do_generate(c);
     } else {
         rc = do_sample(c, nullptr);

@@ -263,4 +263,97 @@ __device__ __forceinline__ float total_cost(const CostParams &p, float j_len, fl
     return total;
 }
 
+// ---- structured sampling: z <- L z for the candidates of a workgroup ------------------
+// CMABase::sampleStandardNormal with a Cholesky factor (L/lmcma.cpp:212-218, applyCovL
+// :857-864).  Over the candidates of a workgroup that is the one dense product of the
+// path, Z (16 x N) = Z0 (16 x N) L^T, and it runs on the matrix cores: the workgroup leaves
+// its normals in LDS, every wave takes output tiles of 16 coordinates and walks the 16-wide
+// blocks of L's rows with v_mfma_f32_16x16x4_f32 (tile t of a lower triangle needs only its
+// first t + 1 blocks), and the products go back through LDS into the callers' lane layout.
+//
+// 256 threads; LANES (16 or 32) lanes own a candidate, lane l the float4 chunks l,
+// l + LANES, ... of its row (zero beyond the row); a workgroup of 8 candidates leaves half
+// of the 16 matrix rows empty.  s_z: [16][16 ntiles + 4] floats.
+typedef float mfma_f32x4 __attribute__((ext_vector_type(4)));
+
+// tile i of this wave: 4 i + wave, then 4 i + 3 - wave, alternating, so that every wave gets
+// the same share of a triangle
+__device__ __forceinline__ int factor_tile(int i, int wave) { return 4 * i + ((i & 1) ? 3 - wave : wave); }
+
+// A second call needs a barrier after the first one's callers have used z (the calls share s_z).
+// (Keeping a wave's blocks of L in registers for the whole kernel was measured slower than
+// reading them from L2 in every call.)
+template <int J, int LANES>
+__device__ __forceinline__ void apply_factor(float4 (&z)[J], const CovFactor &f, float *s_z)
+{
+    constexpr int CANDS = 256 / LANES;
+    constexpr int TPW = J * LANES / 16;  // output tiles per wave: 16 ntiles <= 4 J LANES
+    const int tid = threadIdx.x, lane = tid & (LANES - 1), grp = tid / LANES;
+    const int wl = tid & 63, wave = tid >> 6;
+    const int np = 16 * f.ntiles, ldp = np + 4;  // the pad spreads the 16 rows over the banks
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int col = 4 * (j * LANES + lane);
+        if (col < np) *reinterpret_cast<float4 *>(s_z + grp * ldp + col) = z[j];
+    }
+    if (CANDS < 16) {
+        for (int i = tid; i < (16 - CANDS) * (ldp >> 2); i += 256)
+            reinterpret_cast<float4 *>(s_z + CANDS * ldp)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const int row = wl & 15, kq = 4 * (wl >> 4);
+    const float *a_src = s_z + row * ldp + kq;
+    mfma_f32x4 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        acc[i] = mfma_f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nt = factor_tile(i, wave);
+        if (nt < f.ntiles) {
+            const int nkb = f.kblocks[nt];
+            // lane (row, q) feeds element k = 16 kb + 4 q + s of its row in step s: the four
+            // steps of a block together cover its 16 k
+            const float *b_src = f.L + (size_t)(16 * nt + row) * f.ld + kq;
+            for (int kb0 = 0; kb0 < nkb; kb0 += 4) {
+                // four blocks per step: all eight loads first, then the sixteen products
+                float4 a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kb = kb0 + u < nkb ? kb0 + u : nkb - 1;
+                    a[u] = *reinterpret_cast<const float4 *>(a_src + 16 * kb);
+                    b[u] = *reinterpret_cast<const float4 *>(b_src + 16 * kb);
+                    if (kb0 + u >= nkb) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();  // every wave has read the normals
+    // element r of a lane's result is candidate 4 (lane / 16) + r, coordinate 16 nt + lane % 16
+    if (kq < CANDS) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int nt = factor_tile(i, wave);
+            if (nt < f.ntiles) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_z[(kq + r) * ldp + 16 * nt + row] = acc[i][r];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int col = 4 * (j * LANES + lane);
+        if (col < np) z[j] = *reinterpret_cast<const float4 *>(s_z + grp * ldp + col);
+    }
+}
+
+// floats of LDS apply_factor needs
+__host__ __device__ inline size_t factor_lds_floats(int ntiles) { return (size_t)16 * (16 * ntiles + 4); }
+
 }  // namespace lmcma

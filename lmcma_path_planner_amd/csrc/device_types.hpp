@@ -49,18 +49,6 @@ struct CostParams {
     int grid_words;      // uint32 words of a bit grid (0 when not staged)
 };
 
-struct GenParams {
-    float *rows;              // [n_local][ld], written
-    const float *xmean, *V, *B, *lo, *hi;
-    const SampleScalars *sc;
-    int ld, n_local, m;
-    uint32_t first_candidate, key0, key1;
-    CostParams cost;          // cost.rows is not used: the rows come from LDS
-};
-
-// ---- launchers (each in the .hip file that defines its kernels) -------------
-hipError_t launch_generate(hipStream_t s, const GenParams &g, int dims, bool lds_grid);
-
 // Lower-triangular factor of a structured sampling covariance (applyCovL, L/lmcma.cpp:857-864):
 // z <- L z before the low-rank transform.  L is row-major fp32, (16 ntiles) x ld with
 // ld >= 16 ntiles, zero outside the N x N block; kblocks[t] = 16-wide column blocks of rows
@@ -70,6 +58,19 @@ struct CovFactor {
     int ld, ntiles;
     uint8_t kblocks[32];
 };
+
+struct GenParams {
+    float *rows;              // [n_local][ld], written
+    const float *xmean, *V, *B, *lo, *hi;
+    const SampleScalars *sc;
+    int ld, n_local, m;
+    uint32_t first_candidate, key0, key1;
+    CostParams cost;          // cost.rows is not used: the rows come from LDS
+    CovFactor cov;            // cov.L null: identity
+};
+
+// ---- launchers (each in the .hip file that defines its kernels) -------------
+hipError_t launch_generate(hipStream_t s, const GenParams &g, int dims, bool lds_grid);
 
 // cov: null for the identity
 hipError_t launch_sample(hipStream_t s, float *rows, const float *zbuf, const float *xmean,

@@ -34,7 +34,8 @@ constexpr int kDirectionsPerPass = J == 1 ? 16 : J == 2 ? 8 : 4;
 constexpr int kTile = 256 / kLanes;  // candidates per block pass
 
 // J = float4 chunks per lane (row stride <= 128 J floats)
-template <int J, int D, bool GRID_LDS, bool VB_LDS>
+// COV: the normals pass through the factor of a structured covariance first (apply_factor)
+template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV>
 __global__ __launch_bounds__(256) void k_generate(const GenParams g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
     float *srows = smem;                       // [kTile][ld]
     float *sV = srows + kTile * ld;            // [mp][LDP] when VB_LDS, zero beyond ld and beyond row k
     float *sB = sV + (VB_LDS ? mp * LDP : 0);  // [mp][LDP] when VB_LDS, likewise
-    uint32_t *sbits = reinterpret_cast<uint32_t *>(sB + (VB_LDS ? mp * LDP : 0));
+    float *s_z = sB + (VB_LDS ? mp * LDP : 0);  // [16][16 ntiles + 4] when COV
+    uint32_t *sbits = reinterpret_cast<uint32_t *>(s_z + (COV ? factor_lds_floats(g.cov.ntiles) : 0));
 
     const int lane = threadIdx.x & (kLanes - 1);
     const int slot = threadIdx.x / kLanes;
@@ -128,8 +130,12 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
             z[j] = (chunk < nchunks) ? philox_normals((uint32_t)chunk, g.first_candidate + (uint32_t)c,
                                                       generation, g.key0, g.key1)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
-            acc[j] = make_float4(mk * z[j].x, mk * z[j].y, mk * z[j].z, mk * z[j].w);
         }
+        // (the scoring half of the previous tile does not touch the factor's LDS, and two
+        // barriers separate it from this call)
+        if (COV) apply_factor<J, kLanes>(z, g.cov, s_z);
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[j] = make_float4(mk * z[j].x, mk * z[j].y, mk * z[j].z, mk * z[j].w);
         GEN_STAMP(1);
         __syncthreads();  // staging done (first pass) / previous tile's rows consumed (later passes)
         GEN_STAMP(2);
@@ -278,17 +284,17 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
 
 #undef GEN_STAMP
 
-template <int J, int D, bool GRID_LDS, bool VB_LDS>
+template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV>
 hipError_t launch_t(hipStream_t s, const GenParams &g, size_t lds, int blocks)
 {
     static size_t configured = 48 * 1024;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_generate<J, D, GRID_LDS, VB_LDS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_generate<J, D, GRID_LDS, VB_LDS, COV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL((k_generate<J, D, GRID_LDS, VB_LDS>), dim3(blocks), dim3(256), lds, s, g);
+    hipLaunchKernelGGL((k_generate<J, D, GRID_LDS, VB_LDS, COV>), dim3(blocks), dim3(256), lds, s, g);
     return hipGetLastError();
 }
 
@@ -299,21 +305,28 @@ hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds)
     const size_t rows_b = (size_t)kTile * g.ld * sizeof(float);
     constexpr int U = kDirectionsPerPass<J>;
     const size_t vb_b = 2 * (size_t)((g.m + U - 1) / U * U) * (J * 128) * sizeof(float);  // whole passes of padded rows
+    const bool cov = g.cov.L != nullptr;
+    if (cov) grid_lds = false;  // with a factor the grid is read through L2: half as many variants of the kernel
+    const size_t cov_b = cov ? factor_lds_floats(g.cov.ntiles) * sizeof(float) : 0;
     const size_t grid_b = grid_lds ? (size_t)g.cost.grid_words * sizeof(uint32_t) : 0;
     const size_t budget = 160 * 1024;
-    const bool vb_lds = rows_b + vb_b + grid_b <= budget && g.m <= 32;
+    const bool vb_lds = rows_b + vb_b + grid_b + cov_b <= budget && g.m <= 32;
     if (grid_lds && rows_b + (vb_lds ? vb_b : 0) + grid_b > budget) grid_lds = false;
-    const size_t lds = rows_b + (vb_lds ? vb_b : 0) + (grid_lds ? grid_b : 0);
+    const size_t lds = rows_b + (vb_lds ? vb_b : 0) + (grid_lds ? grid_b : 0) + cov_b;
     // staging is paid per block: one block per CU when something is staged and there
     // are enough tiles, otherwise one block per tile up to eight blocks per CU
     const int blocks = (grid_lds || vb_lds) ? (ntiles < 512 ? ntiles : (grid_lds ? 256 : 512))
                                             : (ntiles < 2048 ? ntiles : 2048);
-    if (grid_lds) {
-        if (vb_lds) return launch_t<J, D, true, true>(s, g, lds, blocks);
-        return launch_t<J, D, true, false>(s, g, lds, blocks);
+    if (cov) {
+        if (vb_lds) return launch_t<J, D, false, true, true>(s, g, lds, blocks);
+        return launch_t<J, D, false, false, true>(s, g, lds, blocks);
     }
-    if (vb_lds) return launch_t<J, D, false, true>(s, g, lds, blocks);
-    return launch_t<J, D, false, false>(s, g, lds, blocks);
+    if (grid_lds) {
+        if (vb_lds) return launch_t<J, D, true, true, false>(s, g, lds, blocks);
+        return launch_t<J, D, true, false, false>(s, g, lds, blocks);
+    }
+    if (vb_lds) return launch_t<J, D, false, true, false>(s, g, lds, blocks);
+    return launch_t<J, D, false, false, false>(s, g, lds, blocks);
 }
 
 template <int D>
@@ -343,6 +356,9 @@ hipError_t launch_generate(hipStream_t s, const GenParams &g, int dims, bool gri
     if (g.ld <= 0 || (g.ld & 3) || g.ld > 512 || g.cost.W < 1 || dims * g.cost.W > g.ld)
         return hipErrorInvalidValue;
     if (grid_lds && (g.cost.grid_type != LMCMA_GRID_BITS || (g.cost.grid_words & 3))) return hipErrorInvalidValue;
+    if (g.cov.L && (g.cov.ntiles < 1 || 16 * g.cov.ntiles < g.ld || g.cov.ntiles > 32 || g.cov.ld < 16 * g.cov.ntiles ||
+                    (g.cov.ld & 3)))
+        return hipErrorInvalidValue;
     switch (dims) {
         case 1: return launch_d<1>(s, g, grid_lds);
         case 2: return launch_d<2>(s, g, grid_lds);

@@ -27,74 +27,6 @@ namespace lmcma {
 
 namespace {
 
-typedef float mfma_f32x4 __attribute__((ext_vector_type(4)));
-
-// z <- L z for the 16 candidates of the workgroup.  z holds the candidates' normals in
-// the lane layout of k_sample (zero beyond the row); s_z is [16][16 ntiles + 4] floats.
-template <int J>
-__device__ __forceinline__ void apply_factor(float4 (&z)[J], const CovFactor &f, float *s_z)
-{
-    const int tid = threadIdx.x, lane16 = tid & 15, grp = tid >> 4;
-    const int wl = tid & 63, wave = tid >> 6;
-    const int np = 16 * f.ntiles, ldp = np + 4;  // the pad spreads the 16 rows over the banks
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const int col = 4 * (j * 16 + lane16);
-        if (col < np) *reinterpret_cast<float4 *>(s_z + grp * ldp + col) = z[j];
-    }
-    __syncthreads();
-    // this wave's tiles: 4 i + wave, then 4 i + 3 - wave, alternating, so that every wave
-    // gets the same share of the triangle
-    const int row = wl & 15, kq = 4 * (wl >> 4);
-    mfma_f32x4 acc[J];
-#pragma unroll
-    for (int i = 0; i < J; ++i) {
-        acc[i] = mfma_f32x4{0.f, 0.f, 0.f, 0.f};
-        const int nt = 4 * i + ((i & 1) ? 3 - wave : wave);
-        if (nt < f.ntiles) {
-            const float *a_src = s_z + row * ldp + kq;
-            const float *b_src = f.L + (size_t)(16 * nt + row) * f.ld + kq;
-            const int nkb = f.kblocks[nt];
-            for (int kb0 = 0; kb0 < nkb; kb0 += 4) {
-                // four blocks per step: all eight loads first, then the sixteen products
-                float4 a[4], b[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int kb = kb0 + u < nkb ? kb0 + u : nkb - 1;
-                    a[u] = *reinterpret_cast<const float4 *>(a_src + 16 * kb);
-                    b[u] = *reinterpret_cast<const float4 *>(b_src + 16 * kb);
-                    if (kb0 + u >= nkb) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    // lane (row, q) feeds element k = 16 kb + 4 q + s of its row in step s: the
-                    // four steps together cover the 16 k of the block
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc[i], 0, 0, 0);
-                }
-            }
-        }
-    }
-    __syncthreads();  // every wave has read the normals
-    // element r of a lane's result is candidate 4 (lane / 16) + r, coordinate 16 nt + lane % 16
-#pragma unroll
-    for (int i = 0; i < J; ++i) {
-        const int nt = 4 * i + ((i & 1) ? 3 - wave : wave);
-        if (nt < f.ntiles) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s_z[(kq + r) * ldp + 16 * nt + row] = acc[i][r];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const int col = 4 * (j * 16 + lane16);
-        if (col < np) z[j] = *reinterpret_cast<const float4 *>(s_z + grp * ldp + col);
-    }
-}
-
 // J = float4 chunks per lane; the row stride ld (a multiple of 4) must be <= 64 J.
 template <int J, bool COV>
 __global__ __launch_bounds__(256) void k_sample(float *__restrict__ rows,
@@ -133,7 +65,7 @@ __global__ __launch_bounds__(256) void k_sample(float *__restrict__ rows,
             z[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    if (COV) apply_factor<J>(z, cov, s_cov);
+    if (COV) apply_factor<J, 16>(z, cov, s_cov);
 #pragma unroll
     for (int j = 0; j < J; ++j) acc[j] = make_float4(mk * z[j].x, mk * z[j].y, mk * z[j].z, mk * z[j].w);
 
