@@ -174,9 +174,19 @@ def main():
     fence()
     timing = ctx.timing_get()
     ctx.timing_enable(False)
-    # an event bracket also reads the time between the two records that is not the kernel
-    # (about 3 us on this stack); an empty bracket measures that share
-    event_overhead_us = ctx.timing_event_overhead(1024) * 1e3
+    # An event bracket also reads time between the two records that is not the kernel (a few
+    # microseconds on this stack).  On one GPU the kernels of a generation run back to back
+    # on one stream, so their durations add up to the measured time per generation: the
+    # share of a bracket that is not kernel is chosen to make them do so.  (An empty bracket
+    # reads more than that share, a bracket around an empty kernel less; both are printed.)
+    empty_bracket_us = ctx.timing_event_overhead(1024) * 1e3
+    timed_steps = args.steps if world == 1 else min(args.steps, 200)
+    brackets_per_step = sum(n for (_, n) in timing.values()) / timed_steps
+    bracket_us_per_step = sum(ms for (ms, _) in timing.values()) * 1e3 / timed_steps
+    if world == 1:
+        event_overhead_us = max((bracket_us_per_step - elapsed / args.steps * 1e6) / brackets_per_step, 0.0)
+    else:
+        event_overhead_us = 0.0   # collectives sit between the kernels: the brackets are reported as read
     st = ctx.opt_get()
 
     if rank == 0:
@@ -216,7 +226,8 @@ def main():
                          "bytes_per_launch": per_kernel[dominant]["bytes"],
                          "avg_launch_us": per_kernel[dominant]["avg_us"],
                          "event_bracket_us": per_kernel[dominant]["bracket_us"],
-                         "empty_bracket_us": event_overhead_us},
+                         "bracket_overhead_us": event_overhead_us,
+                         "empty_bracket_us": empty_bracket_us},
             "kernels": per_kernel,
             "generation_bytes_per_candidate": prob.algorithmic_bytes_per_candidate(lam_local),
             "final": {"generations": st["itr"], "best_f": st["best_f"], "sigma": st["sigma"]},

@@ -5,10 +5,13 @@
 
 Writes profiles/<tag>_kernel_stats.csv (the --kernel-trace --stats summary as is),
 profiles/<tag>_hbm_traffic.csv (per kernel: launches, mean FETCH_SIZE and WRITE_SIZE
-in KB per launch, as the counters report them) and profiles/traffic_cfg2.json (bytes
-per launch per kernel class, FETCH_SIZE + WRITE_SIZE, read by bench.py).
-FETCH_SIZE on gfx950 reports half the bytes of wide (16 B/lane) coalesced streaming
-reads; the figures here are the raw counter values, not corrected."""
+in KB per launch as the counters report them, and the corrected bytes per launch) and
+profiles/traffic_cfg2.json (corrected bytes per launch per kernel class, read by bench.py).
+Correction: FETCH_SIZE on gfx950 reports half the bytes of wide (16 B/lane) coalesced
+streaming reads, which is how these kernels read everything of any size, so
+bytes = 2 * FETCH_SIZE + WRITE_SIZE (both in KB of 1024 bytes).  Narrower reads (the
+4-byte row gathers of the ranking kernel) are then counted at up to twice their size:
+the figure is an upper bound on the traffic."""
 import collections
 import csv
 import glob
@@ -45,13 +48,13 @@ def main():
         fe, wr = pmc(sys.argv[3]), pmc(sys.argv[4])
         per_class = collections.defaultdict(float)
         with open(os.path.join(HERE, tag + "_hbm_traffic.csv"), "w") as out:
-            out.write("kernel,launches,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch\n")
+            out.write("kernel,launches,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,corrected_bytes_per_launch\n")
             for k in sorted(fe):
                 f_kb = fe[k][1] / fe[k][0]
                 w_kb = wr[k][1] / wr[k][0] if k in wr else 0.0
-                out.write("%s,%d,%.3f,%.3f\n" % (k, fe[k][0], f_kb, w_kb))
+                out.write("%s,%d,%.3f,%.3f,%.0f\n" % (k, fe[k][0], f_kb, w_kb, (2 * f_kb + w_kb) * 1024.0))
                 if k in CLASS_OF:
-                    per_class[CLASS_OF[k]] += (f_kb + w_kb) * 1024.0
+                    per_class[CLASS_OF[k]] += (2 * f_kb + w_kb) * 1024.0
         json.dump({k: round(v) for k, v in per_class.items()}, open(os.path.join(HERE, "traffic_cfg2.json"), "w"),
                   indent=1, sort_keys=True)
 
