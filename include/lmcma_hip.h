@@ -94,6 +94,18 @@ int lmcma_hip_destroy(lmcma_hip_ctx *ctx);
 int lmcma_hip_set_grid(lmcma_hip_ctx *ctx, const void *cells, int nx, int ny,
                        int nz, int cell_type, double c_obs);
 
+/* The same cost map built on the device from an occupancy grid: what the
+ * reference does with dynamicEDT3D before planning (S/...path_planner.cpp:
+ * 299-321: DynamicEDT3D::initializeMap + update, then getDistance of every
+ * cell into EDT_Matrix) followed by the state cost 1 / clearance (:655-668).
+ * occ is [nz][ny][nx] bytes, non-zero = occupied; the distance of a cell is the
+ * exact Euclidean distance, in cells, to the nearest occupied one (0 on it; 1e6
+ * when the grid holds none); the installed map is LMCMA_GRID_F32 with
+ * 1 / max(distance, d_min) per cell.  dist_out (optional, host, cells floats)
+ * receives the distances.  Extents up to 1024 per axis.                        */
+int lmcma_hip_set_grid_from_occupancy(lmcma_hip_ctx *ctx, const uint8_t *occ, int nx,
+                                      int ny, int nz, double d_min, float *dist_out);
+
 /* loBounds / hiBounds of the constructor (L/lmcma.hpp:131-133), applied like
  * CMABase::applyBoundaries (L/lmcma.cpp:220-230).  Either may be NULL.         */
 int lmcma_hip_set_bounds(lmcma_hip_ctx *ctx, const double *lo, const double *hi);

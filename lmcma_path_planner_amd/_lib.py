@@ -80,6 +80,7 @@ SIGNATURES = {
     "lmcma_hip_destroy": (_i, [_vp]),
     "lmcma_hip_set_grid": (_i, [_vp, _vp, _i, _i, _i, _i, ctypes.c_double]),
     "lmcma_hip_set_bounds": (_i, [_vp, c_double_p, c_double_p]),
+    "lmcma_hip_set_grid_from_occupancy": (_i, [_vp, ctypes.c_void_p, _i, _i, _i, ctypes.c_double, ctypes.c_void_p]),
     "lmcma_hip_set_cov_factor": (_i, [_vp, c_double_p]),
     "lmcma_hip_set_state": (_i, [_vp, c_double_p, ctypes.c_double, c_double_p, c_double_p, c_double_p, _i,
                                  ctypes.c_double]),

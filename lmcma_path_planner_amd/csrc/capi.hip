@@ -624,6 +624,66 @@ int lmcma_hip_set_grid(lmcma_hip_ctx *c, const void *cells, int nx, int ny, int 
     return LMCMA_HIP_OK;
 }
 
+int lmcma_hip_set_grid_from_occupancy(lmcma_hip_ctx *c, const uint8_t *occ, int nx, int ny, int nz, double d_min,
+                                      float *dist_out)
+{
+    CTX_TRY(c);
+    if (c->D < 1) return fail(LMCMA_HIP_ERR_STATE, "this context has no trajectory cost (dims = 0)");
+    if (!occ || nx < 1 || ny < 1 || nz < 1) return fail(LMCMA_HIP_ERR_ARG, "bad grid extent");
+    if (nx > 1024 || ny > 1024 || nz > 1024) return fail(LMCMA_HIP_ERR_UNSUPPORTED, "extents up to 1024 cells per axis");
+    if (c->D < 3 && nz != 1) return fail(LMCMA_HIP_ERR_ARG, "nz must be 1 for a 1-D or 2-D problem");
+    if (c->D < 2 && ny != 1) return fail(LMCMA_HIP_ERR_ARG, "ny must be 1 for a 1-D problem");
+    if (!(d_min > 0.0)) return fail(LMCMA_HIP_ERR_ARG, "d_min must be positive");
+    const long cells_n = (long)nx * ny * nz;
+    if (cells_n > (1l << 30)) return fail(LMCMA_HIP_ERR_UNSUPPORTED, "grid larger than 2^30 cells");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);
+    if (c->grid) { (void)hipFree(c->grid); c->grid = nullptr; }
+    // scratch of the transform: the occupancy bytes, squared distances, and the distances if asked for
+    uint8_t *d_occ = nullptr;
+    uint32_t *d_d2 = nullptr;
+    float *d_dist = nullptr;
+    auto release = [&]() {
+        if (d_occ) (void)hipFree(d_occ);
+        if (d_d2) (void)hipFree(d_d2);
+        if (d_dist) (void)hipFree(d_dist);
+    };
+    hipError_t e = hipMalloc(&d_occ, (size_t)cells_n);
+    if (e == hipSuccess) e = hipMalloc(&d_d2, (size_t)cells_n * sizeof(uint32_t));
+    if (e == hipSuccess && dist_out) e = hipMalloc(&d_dist, (size_t)cells_n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&c->grid, (size_t)cells_n * sizeof(float) + 16);
+    if (e == hipSuccess) e = hipMemcpy(d_occ, occ, (size_t)cells_n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_edt(c->stream, d_occ, nx, ny, nz, d_min, d_d2, d_dist, (float *)c->grid);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && dist_out)
+        e = hipMemcpy(dist_out, d_dist, (size_t)cells_n * sizeof(float), hipMemcpyDeviceToHost);
+    c->nx = nx; c->ny = ny; c->nz = nz;
+    c->grid_type = LMCMA_GRID_F32;
+    c->grid_words = 0;
+    c->grid_lds = false;
+    c->c_obs = 1.f;
+    c->grid_bytes = (size_t)cells_n * sizeof(float);
+    // the fixed endpoints' cost: two cells of the finished map
+    float ends[2] = {0.f, 0.f};
+    if (e == hipSuccess) {
+        auto cl = [](double v, int n) { return (int)nearbyintf(fminf(fmaxf((float)v, 0.f), (float)(n - 1))); };
+        const double *pts[2] = {c->cfg.start, c->cfg.goal};
+        for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+            const long cell = ((long)(c->D > 2 ? cl(pts[i][2], nz) : 0) * ny + (c->D > 1 ? cl(pts[i][1], ny) : 0)) * nx +
+                              cl(pts[i][0], nx);
+            e = hipMemcpy(&ends[i], (const float *)c->grid + cell, sizeof(float), hipMemcpyDeviceToHost);
+        }
+    }
+    release();
+    if (e != hipSuccess) {
+        if (c->grid) { (void)hipFree(c->grid); c->grid = nullptr; }
+        return fail(LMCMA_HIP_ERR_RUNTIME, std::string("set_grid_from_occupancy: ") + hipGetErrorString(e));
+    }
+    c->c_start = ends[0];
+    c->c_goal = ends[1];
+    return LMCMA_HIP_OK;
+}
+
 int lmcma_hip_set_bounds(lmcma_hip_ctx *c, const double *lo, const double *hi)
 {
     CTX_TRY(c);

@@ -97,6 +97,18 @@ class HipContext:
         check_hip(self.lib.lmcma_hip_set_grid(self._h, words.ctypes.data_as(ctypes.c_void_p), nx, ny, nz,
                                               GRID_BITS, float(c_obs)), "lmcma_hip_set_grid")
 
+    def set_grid_from_occupancy(self, occ, d_min=0.5, want_distances=False):
+        """Builds the clearance cost map 1 / max(distance, d_min) on the device from an occupancy
+        array shaped (nx,), (ny, nx) or (nz, ny, nx); returns the distances when asked for."""
+        occ = np.ascontiguousarray(np.asarray(occ) != 0, dtype=np.uint8)
+        shape = (1,) * (3 - occ.ndim) + occ.shape
+        nz, ny, nx = shape
+        dist = np.empty(shape, dtype=np.float32) if want_distances else None
+        check_hip(self.lib.lmcma_hip_set_grid_from_occupancy(
+            self._h, occ.ctypes.data_as(ctypes.c_void_p), nx, ny, nz, float(d_min),
+            dist.ctypes.data_as(ctypes.c_void_p) if want_distances else None), "lmcma_hip_set_grid_from_occupancy")
+        return dist.reshape(occ.shape) if want_distances else None
+
     def set_bounds(self, lo, hi):
         lo, hi = _f64(lo), _f64(hi)
         check_hip(self.lib.lmcma_hip_set_bounds(self._h, _dp(lo), _dp(hi)), "lmcma_hip_set_bounds")

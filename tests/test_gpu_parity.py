@@ -259,6 +259,47 @@ def test_cost_3d_occupancy_and_esdf(hip, oracle):
     _check_costs(hip, oracle, 1, 16, line[0], [0.0], [39.0], rows1, lam=32)
 
 
+@pytest.mark.parametrize("shape,kind", [((100, 100), "two_bar"), ((512, 512), "boxes"), ((48, 48, 48), "boxes"),
+                                        ((1, 37), "sparse"), ((33, 70, 129), "sparse"), ((20, 24), "empty"),
+                                        ((600, 40), "sparse"), ((128, 128, 128), "boxes")])
+def test_device_distance_transform_is_exact(hip, oracle, shape, kind):
+    """Squared Euclidean distances are integers, so the device transform must give the oracle's
+    distances (exact lower envelopes in fp64) bit for bit, and the installed cost map must score
+    rows like a host-built map."""
+    from lmcma_path_planner_amd import grids
+    rng = np.random.default_rng(17)
+    dims = len(shape) if shape[0] > 1 else 1
+    start = [float(shape[-1] - 1), 0.0, 0.0][:dims]
+    goal = [0.0] + [float(n - 1) for n in shape[::-1][1:]]
+    goal = goal[:dims]
+    if kind == "two_bar":
+        occ = oracle.two_bar_map(shape[0])
+    elif kind == "boxes":
+        occ = oracle.random_boxes(np.zeros(shape, dtype=np.uint8), 5, 0.15, start, goal)
+    elif kind == "sparse":
+        occ = (rng.random(shape) < 0.002).astype(np.uint8)
+        occ.flat[rng.integers(occ.size)] = 1
+    else:
+        occ = np.zeros(shape, dtype=np.uint8)
+    want = oracle.edt_exact(occ)
+    if kind == "empty":
+        assert np.all(want == np.float32(1.0e6))
+    W = 8
+    ctx = hip.HipContext(dims * W, 64, 4, dims=dims, waypoints=W, start=start, goal=goal)
+    got = ctx.set_grid_from_occupancy(occ if dims > 1 else occ[0], d_min=0.5, want_distances=True)
+    np.testing.assert_array_equal(got.reshape(want.shape), want)
+    # scoring against the device-built map equals scoring against the same map built on the host
+    rows = np.stack([rng.uniform(0, n - 1, size=(50, W)) for n in shape[::-1][:dims]], axis=1).reshape(50, dims * W)
+    rows = rows.astype(np.float32)
+    a, ta = ctx.score_rows(rows)
+    cost_map = grids.state_cost_from_distance(want, 0.5)
+    ctx.set_grid(cost_map if dims > 1 else cost_map[0])
+    b, tb = ctx.score_rows(rows)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(ta, tb)
+    ctx.close()
+
+
 def _reference_order(costs):
     c = np.asarray(costs, dtype=np.float32).astype(np.float64)
     c = np.where(np.isnan(c), np.inf, c)
