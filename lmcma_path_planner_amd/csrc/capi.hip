@@ -649,7 +649,7 @@ int lmcma_hip_set_grid_from_occupancy(lmcma_hip_ctx *c, const uint8_t *occ, int 
         if (d_dist) (void)hipFree(d_dist);
     };
     hipError_t e = hipMalloc(&d_occ, (size_t)cells_n);
-    if (e == hipSuccess) e = hipMalloc(&d_d2, (size_t)cells_n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_d2, 2 * (size_t)cells_n * sizeof(uint32_t));
     if (e == hipSuccess && dist_out) e = hipMalloc(&d_dist, (size_t)cells_n * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->grid, (size_t)cells_n * sizeof(float) + 16);
     if (e == hipSuccess) e = hipMemcpy(d_occ, occ, (size_t)cells_n, hipMemcpyHostToDevice);

@@ -79,7 +79,7 @@ hipError_t launch_sample(hipStream_t s, float *rows, const float *zbuf, const fl
                          uint64_t seed, const CovFactor *cov);
 
 // Exact Euclidean distance transform (k_edt.hip).  occ: [nz][ny][nx] bytes on the device;
-// d2: [cells] scratch; dist, cost: [cells] floats or null; cost = 1 / max(dist, d_min).
+// d2: [2][cells] scratch; dist, cost: [cells] floats or null; cost = 1 / max(dist, d_min).
 hipError_t launch_edt(hipStream_t s, const uint8_t *occ, int nx, int ny, int nz, double d_min, uint32_t *d2,
                       float *dist, float *cost);
 
