@@ -95,6 +95,22 @@ int lmcma_grid_8ssedt(const uint8_t *inside, int width, int height, int32_t *sig
 /* state cost 1 / max(distance, d_min) per cell (S/:667 with the distance clamped) */
 int lmcma_grid_state_cost(const float *dist, long cells, double d_min, float *cost);
 
+/* ---- map files (host) ---------------------------------------------------------------
+ * A binvox voxel file as the reference's converter reads it (binvox2bt.cpp:164-255 in
+ * the same directory as S/): header keywords dim / translate / scale / data, then
+ * (value, count) byte pairs, voxel i at x = i / (w h), z = (i / w) % h, y = i % w.
+ * dims receives the extents along x, y, z; occ (NULL to read the header only, else
+ * at least dims[0] dims[1] dims[2] bytes, `capacity` of them available) receives the
+ * grid as [z][y][x].  Returns the number of occupied voxels, or < 0: -2 cannot open,
+ * -3 malformed header, -4 capacity too small, -5 truncated data.                     */
+int lmcma_grid_read_binvox(const char *path, int dims[3], double translate[3], double *scale, uint8_t *occ,
+                           long capacity);
+/* An uncompressed BMP image (8-bit palette, 24- or 32-bit pixels) thresholded like
+ * Signed_Distance_Fields_test (S/:507-523): a pixel is marked when green < 128.
+ * marked (NULL for the size only) is [height][width], first row = top of the image.
+ * Returns the number of marked pixels, or < 0 as above.                              */
+int lmcma_grid_read_bmp(const char *path, int *width, int *height, uint8_t *marked, long capacity);
+
 #ifdef __cplusplus
 }
 #endif

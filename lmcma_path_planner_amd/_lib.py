@@ -138,6 +138,10 @@ SIGNATURES = {
     "lmcma_grid_edt": (_i, [c_uint8_p, _i, _i, _i, c_float_p]),
     "lmcma_grid_8ssedt": (_i, [c_uint8_p, _i, _i, c_int32_p, c_double_p]),
     "lmcma_grid_state_cost": (_i, [c_float_p, ctypes.c_long, ctypes.c_double, c_float_p]),
+    "lmcma_grid_read_binvox": (_i, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), c_double_p, c_double_p, c_uint8_p,
+                                    ctypes.c_long]),
+    "lmcma_grid_read_bmp": (_i, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                 c_uint8_p, ctypes.c_long]),
 }
 
 _lib = None

@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <limits>
+#include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "lmcma_opt.h"
@@ -226,6 +228,103 @@ int lmcma_grid_state_cost(const float *dist, long cells, double d_min, float *co
     // check (S/:602), here the clearance is floored at d_min instead
     for (long i = 0; i < cells; ++i) cost[i] = (float)(1.0 / std::max((double)dist[i], d_min));
     return 0;
+}
+
+// ---- map files ------------------------------------------------------------------------
+
+// binvox: text header ("#binvox 1", "dim d h w", "translate", "scale", "data") then
+// (value, count) byte pairs; voxel i is x = i / (w h), z = (i / w) % h, y = i % w
+// (binvox2bt.cpp:164-255 of the reference's planner package)
+int lmcma_grid_read_binvox(const char *path, int dims[3], double translate[3], double *scale, uint8_t *occ,
+                           long capacity)
+{
+    if (!path || !dims) return -1;
+    FILE *f = fopen(path, "rb");
+    if (!f) return -2;
+    struct Closer { FILE *f; ~Closer() { fclose(f); } } closer{f};
+    char word[64];
+    int version = 0;
+    if (fscanf(f, "%63s %d", word, &version) != 2 || strcmp(word, "#binvox") != 0) return -3;
+    int depth = -1, height = -1, width = -1;
+    double t[3] = {0, 0, 0}, sc = 1.0;
+    bool data = false;
+    while (!data && fscanf(f, "%63s", word) == 1) {
+        if (!strcmp(word, "data")) data = true;
+        else if (!strcmp(word, "dim")) { if (fscanf(f, "%d %d %d", &depth, &height, &width) != 3) return -3; }
+        else if (!strcmp(word, "translate")) { if (fscanf(f, "%lf %lf %lf", &t[0], &t[1], &t[2]) != 3) return -3; }
+        else if (!strcmp(word, "scale")) { if (fscanf(f, "%lf", &sc) != 1) return -3; }
+        else { int ch; while ((ch = fgetc(f)) != EOF && ch != '\n') {} }  // unknown keyword: skip its line
+    }
+    if (!data || depth < 1 || height < 1 || width < 1) return -3;
+    dims[0] = depth; dims[1] = width; dims[2] = height;  // extents along x, y, z
+    if (translate) std::copy(t, t + 3, translate);
+    if (scale) *scale = sc;
+    const long size = (long)depth * height * width;
+    if (!occ) return 0;
+    if (capacity < size) return -4;
+    if (fgetc(f) == EOF) return -3;  // the line feed after "data"
+    long index = 0, occupied = 0;
+    const int nx = depth, ny = width;
+    while (index < size) {
+        const int value = fgetc(f), count = fgetc(f);
+        if (value == EOF || count == EOF) return -5;  // truncated
+        if (index + count > size) return -5;
+        for (long i = index; i < index + count; ++i) {
+            const long y = i % width, z = (i / width) % height, x = i / ((long)width * height);
+            occ[(z * ny + y) * nx + x] = value ? 1 : 0;
+        }
+        if (value) occupied += count;
+        index += count;
+    }
+    return occupied > 0x7fffffff ? 0x7fffffff : (int)occupied;
+}
+
+// Uncompressed BMP (8-bit palette, 24- or 32-bit pixels); a pixel is marked when its green
+// channel is below 128, the test of Signed_Distance_Fields_test (S/:507-523).  Rows come
+// out top to bottom like the SDL surface the reference walks.
+int lmcma_grid_read_bmp(const char *path, int *width, int *height, uint8_t *marked, long capacity)
+{
+    if (!path || !width || !height) return -1;
+    FILE *f = fopen(path, "rb");
+    if (!f) return -2;
+    struct Closer { FILE *f; ~Closer() { fclose(f); } } closer{f};
+    unsigned char h[54];
+    if (fread(h, 1, 54, f) != 54 || h[0] != 'B' || h[1] != 'M') return -3;
+    auto u32 = [&](int at) { return (uint32_t)h[at] | (uint32_t)h[at + 1] << 8 | (uint32_t)h[at + 2] << 16 | (uint32_t)h[at + 3] << 24; };
+    auto u16 = [&](int at) { return (uint32_t)h[at] | (uint32_t)h[at + 1] << 8; };
+    const uint32_t offset = u32(10), header = u32(14);
+    const int32_t w = (int32_t)u32(18), hh = (int32_t)u32(22);
+    const uint32_t bpp = u16(28), compression = u32(30);
+    if (header < 40 || w < 1 || hh == 0 || (compression != 0 && compression != 3)) return -3;
+    if (bpp != 8 && bpp != 24 && bpp != 32) return -3;
+    const int H = hh < 0 ? -hh : hh;
+    *width = w;
+    *height = H;
+    if (!marked) return 0;
+    if (capacity < (long)w * H) return -4;
+    std::vector<unsigned char> palette;
+    if (bpp == 8) {
+        uint32_t colours = u32(46);
+        if (colours == 0 || colours > 256) colours = 256;
+        palette.resize(4 * 256, 0);
+        if (fseek(f, 14 + (long)header, SEEK_SET) != 0 || fread(palette.data(), 4, colours, f) != colours) return -5;
+    }
+    const size_t stride = (((size_t)w * bpp + 31) / 32) * 4;
+    std::vector<unsigned char> row(stride);
+    if (fseek(f, (long)offset, SEEK_SET) != 0) return -5;
+    int count = 0;
+    for (int r = 0; r < H; ++r) {
+        if (fread(row.data(), 1, stride, f) != stride) return -5;
+        const int y = hh < 0 ? r : H - 1 - r;  // positive height: the file starts with the bottom row
+        for (int x = 0; x < w; ++x) {
+            // pixels are stored blue, green, red(, alpha)
+            const unsigned char g = bpp == 8 ? palette[4 * row[x] + 1] : row[(size_t)x * (bpp / 8) + 1];
+            const uint8_t m = g < 128 ? 1 : 0;
+            marked[(size_t)y * w + x] = m;
+            count += m;
+        }
+    }
+    return count;
 }
 
 }  // extern "C"

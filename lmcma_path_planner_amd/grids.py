@@ -5,6 +5,7 @@ Grids are indexed ``[z][y][x]`` (row = y, col = x) like the reference's
 (sample_based_optimisation_based_path_planner.cpp:599-602).
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -57,6 +58,59 @@ def ssedt8(inside):
                                      d.ctypes.data_as(c_double_p)) != 0:
         raise ValueError("lmcma_grid_8ssedt: bad arguments")
     return sd, d
+
+
+def read_binvox(path):
+    """(occ[z][y][x] uint8, translate[3], scale) of a binvox voxel file."""
+    dims = (ctypes.c_int * 3)()
+    tr = np.zeros(3)
+    sc = ctypes.c_double(1.0)
+    lib = _lib.load()
+    rc = lib.lmcma_grid_read_binvox(os.fsencode(path), dims, tr.ctypes.data_as(c_double_p), ctypes.byref(sc), None, 0)
+    if rc < 0:
+        raise ValueError("read_binvox(%s): error %d" % (path, rc))
+    nx, ny, nz = dims[0], dims[1], dims[2]
+    occ = np.zeros((nz, ny, nx), dtype=np.uint8)
+    rc = lib.lmcma_grid_read_binvox(os.fsencode(path), dims, tr.ctypes.data_as(c_double_p), ctypes.byref(sc), _u8p(occ),
+                                    occ.size)
+    if rc < 0:
+        raise ValueError("read_binvox(%s): error %d" % (path, rc))
+    return occ, tr, sc.value
+
+
+def write_binvox(path, occ, translate=(0.0, 0.0, 0.0), scale=1.0):
+    """Writes occ[z][y][x] as a binvox file (voxel order x-major, then z, then y; runs of at most 255)."""
+    occ = np.asarray(occ)
+    nz, ny, nx = occ.shape
+    flat = (occ.transpose(2, 0, 1) != 0).astype(np.uint8).reshape(-1)     # [x][z][y]
+    edges = np.flatnonzero(np.diff(flat)) + 1
+    starts = np.concatenate([[0], edges])
+    lengths = np.diff(np.concatenate([starts, [flat.size]]))
+    with open(path, "wb") as f:
+        f.write(("#binvox 1\ndim %d %d %d\ntranslate %.17g %.17g %.17g\nscale %.17g\ndata\n"
+                 % ((nx, nz, ny) + tuple(translate) + (scale,))).encode())
+        out = bytearray()
+        for st, ln in zip(starts.tolist(), lengths.tolist()):
+            v = int(flat[st])
+            while ln > 0:
+                c = min(ln, 255)
+                out += bytes((v, c))
+                ln -= c
+        f.write(bytes(out))
+
+
+def read_bmp(path):
+    """Pixels of a BMP image with green < 128, as a (height, width) uint8 array, top row first."""
+    w, h = ctypes.c_int(0), ctypes.c_int(0)
+    lib = _lib.load()
+    rc = lib.lmcma_grid_read_bmp(os.fsencode(path), ctypes.byref(w), ctypes.byref(h), None, 0)
+    if rc < 0:
+        raise ValueError("read_bmp(%s): error %d" % (path, rc))
+    marked = np.zeros((h.value, w.value), dtype=np.uint8)
+    rc = lib.lmcma_grid_read_bmp(os.fsencode(path), ctypes.byref(w), ctypes.byref(h), _u8p(marked), marked.size)
+    if rc < 0:
+        raise ValueError("read_bmp(%s): error %d" % (path, rc))
+    return marked
 
 
 def state_cost_from_distance(dist, d_min=0.5):

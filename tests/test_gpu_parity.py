@@ -300,6 +300,36 @@ def test_device_distance_transform_is_exact(hip, oracle, shape, kind):
     ctx.close()
 
 
+def test_voxel_file_to_clearance_map_to_planned_path(hip, oracle, tmp_path):
+    """The steps before the path, end to end: a binvox voxel model (the format of the reference's
+    room model) is read, its clearance map is built on the device, and the device loop plans
+    through it; the result is scored by the CPU oracle on a host-built map."""
+    from lmcma_path_planner_amd import grids
+    size, W = 40, 16
+    start, goal = [39.0, 0.0, 0.0], [0.0, 39.0, 39.0]
+    occ0 = grids.add_random_boxes(grids.two_bar_map(size, size), 11, 0.12, start, goal)
+    path = tmp_path / "model.binvox"
+    grids.write_binvox(str(path), occ0, translate=(-1.5, -2.0, -0.001), scale=4.0)
+    occ, tr, sc = grids.read_binvox(str(path))
+    np.testing.assert_array_equal(occ, occ0)
+    N, lam, m = 3 * W, 256, 8
+    t = np.arange(1, W + 1) / (W + 1)
+    x0 = np.concatenate([start[d] + t * (goal[d] - start[d]) for d in range(3)])
+    ctx = hip.HipContext(N, lam, m, dims=3, waypoints=W, start=start, goal=goal, seed=3)
+    ctx.set_grid_from_occupancy(occ, d_min=0.5)
+    ctx.set_bounds(np.zeros(N), np.full(N, size - 1.0))
+    ctx.opt_init(x0, 2.0)
+    ctx.run(150)
+    st = ctx.opt_get()
+    cost_map = oracle.edt_exact(occ)
+    cost_map = (1.0 / np.maximum(cost_map.astype(np.float64), 0.5)).astype(np.float32)
+    co = oracle.CostOracle(3, W, cost_map, start, goal)
+    straight, _ = co.cost(x0)
+    final, _ = co.cost(st["xmean"])
+    assert st["itr"] == 150 and final < straight
+    ctx.close()
+
+
 def _reference_order(costs):
     c = np.asarray(costs, dtype=np.float32).astype(np.float64)
     c = np.where(np.isnan(c), np.inf, c)

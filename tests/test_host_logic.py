@@ -129,3 +129,87 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in text and "lmcma_oracle" not in text and "orc_" not in text, f
+
+
+def _write_binvox(path, vox, translate=(0.5, -1.0, 2.0), scale=3.0):
+    """vox[x][z][y] in file order (binvox2bt.cpp:252-255), run-length encoded."""
+    d, h, w = vox.shape
+    flat = vox.reshape(-1)
+    with open(path, "wb") as f:
+        f.write(b"#binvox 1\ndim %d %d %d\ntranslate %g %g %g\nscale %g\ndata\n" % ((d, h, w) + tuple(translate) + (scale,)))
+        i = 0
+        while i < flat.size:
+            j = i
+            while j < flat.size and flat[j] == flat[i] and j - i < 255:
+                j += 1
+            f.write(bytes([int(flat[i]), j - i]))
+            i = j
+
+
+def test_binvox_reader_round_trip(tmp_path):
+    from lmcma_path_planner_amd import grids
+    rng = np.random.default_rng(4)
+    vox = (rng.random((5, 7, 6)) < 0.3).astype(np.uint8)   # [x][z][y]
+    vox[2, :, :] = 1                                        # a long run
+    path = tmp_path / "a.binvox"
+    _write_binvox(path, vox)
+    occ, tr, sc = grids.read_binvox(str(path))
+    assert occ.shape == (7, 6, 5)                           # [z][y][x]
+    np.testing.assert_array_equal(occ, vox.transpose(1, 2, 0))
+    np.testing.assert_allclose(tr, [0.5, -1.0, 2.0])
+    assert sc == 3.0
+    # truncated data and a wrong magic are reported, not read past
+    data = path.read_bytes()
+    (tmp_path / "cut.binvox").write_bytes(data[:-4])
+    with pytest.raises(ValueError):
+        grids.read_binvox(str(tmp_path / "cut.binvox"))
+    (tmp_path / "bad.binvox").write_bytes(b"#notvox 1\n")
+    with pytest.raises(ValueError):
+        grids.read_binvox(str(tmp_path / "bad.binvox"))
+    with pytest.raises(ValueError):
+        grids.read_binvox(str(tmp_path / "missing.binvox"))
+
+
+def _write_bmp24(path, rgb, top_down=False):
+    h, w, _ = rgb.shape
+    stride = (w * 3 + 3) // 4 * 4
+    rows = rgb if top_down else rgb[::-1]
+    body = b"".join(bytes(r[:, ::-1].reshape(-1).tolist()) + b"\0" * (stride - 3 * w) for r in rows)
+    import struct
+    header = struct.pack("<2sIHHI", b"BM", 54 + len(body), 0, 0, 54)
+    info = struct.pack("<IiiHHIIiiII", 40, w, -h if top_down else h, 1, 24, 0, len(body), 2835, 2835, 0, 0)
+    with open(path, "wb") as f:
+        f.write(header + info + body)
+
+
+def test_bmp_reader_thresholds_green_like_the_reference(tmp_path):
+    from lmcma_path_planner_amd import grids
+    rng = np.random.default_rng(9)
+    rgb = rng.integers(0, 256, size=(9, 13, 3), dtype=np.uint8)
+    rgb[0, 0] = (255, 127, 255)     # green just below the threshold: marked
+    rgb[0, 1] = (0, 128, 0)         # at the threshold: not marked
+    for top_down in (False, True):
+        path = tmp_path / ("img%d.bmp" % top_down)
+        _write_bmp24(path, rgb, top_down)
+        marked = grids.read_bmp(str(path))
+        np.testing.assert_array_equal(marked, (rgb[:, :, 1] < 128).astype(np.uint8))
+    with pytest.raises(ValueError):
+        grids.read_bmp(str(tmp_path / "none.bmp"))
+
+
+REFERENCE_MAPS = "/root/reference/sample_based_optimisation_based_path_planner"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_MAPS), reason="the reference's map files are only present in the build container")
+def test_readers_on_the_reference_map_files():
+    """The reference's own inputs: the 100 x 100 problem images its node loads
+    (sample_based_optimisation_based_path_planner.cpp:1619) and its 256^3 room model."""
+    from lmcma_path_planner_amd import grids
+    for name in ("problem1.bmp", "problem2.bmp"):
+        marked = grids.read_bmp(os.path.join(REFERENCE_MAPS, "images", name))
+        assert marked.shape == (100, 100)
+        assert 0 < marked.sum() < marked.size
+    occ, tr, sc = grids.read_binvox(os.path.join(REFERENCE_MAPS, "files/mesh_files/room.binvox"))
+    assert occ.shape == (256, 256, 256) and sc == 4.0
+    np.testing.assert_allclose(tr, [-1.5, -2.0, -0.001])
+    assert 0 < occ.sum() < occ.size // 4
