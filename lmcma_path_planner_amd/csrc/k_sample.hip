@@ -69,31 +69,59 @@ __global__ __launch_bounds__(256) void k_sample(float *__restrict__ rows,
 #pragma unroll
     for (int j = 0; j < J; ++j) acc[j] = make_float4(mk * z[j].x, mk * z[j].y, mk * z[j].z, mk * z[j].w);
 
-    for (int t = 0; t < k; ++t) {
-        const float4 *v = reinterpret_cast<const float4 *>(V + (size_t)t * ld);
-        const float4 *b = reinterpret_cast<const float4 *>(B + (size_t)t * ld);
-        float d = 0.f;
+    // U direction vectors per pass: every dot product is with z itself, so the loads, products
+    // and lane reductions of a pass are independent and overlap; the rank-one terms are still
+    // added in the order t = 0, 1, 2, ...  Rows past k - 1 are read at a clamped index and dropped.
+    constexpr int U = J <= 2 ? 8 : 4;
+    for (int t0 = 0; t0 < k; t0 += U) {
+        float4 vv[U][J];
+        float d[U];
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const int chunk = j * 16 + lane;
-            if (chunk < nchunks) {
-                const float4 vv = v[chunk];
-                d = fmaf(vv.x, z[j].x, d);
-                d = fmaf(vv.y, z[j].y, d);
-                d = fmaf(vv.z, z[j].z, d);
-                d = fmaf(vv.w, z[j].w, d);
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u < k ? t0 + u : k - 1;
+            const float4 *v = reinterpret_cast<const float4 *>(V + (size_t)t * ld);
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int chunk = j * 16 + lane;
+                vv[u][j] = v[chunk < nchunks ? chunk : nchunks - 1];
             }
         }
-        d = group_sum<16>(d);
+        asm volatile("" ::: "memory");  // all loads of the pass are requested before the first product
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const int chunk = j * 16 + lane;
-            if (chunk < nchunks) {
-                const float4 bb = b[chunk];
-                acc[j].x = fmaf(d, bb.x, acc[j].x);
-                acc[j].y = fmaf(d, bb.y, acc[j].y);
-                acc[j].z = fmaf(d, bb.z, acc[j].z);
-                acc[j].w = fmaf(d, bb.w, acc[j].w);
+        for (int u = 0; u < U; ++u) {
+            d[u] = 0.f;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                // z is zero beyond the row, so a chunk read at a clamped index adds nothing
+                d[u] = fmaf(vv[u][j].x, z[j].x, d[u]);
+                d[u] = fmaf(vv[u][j].y, z[j].y, d[u]);
+                d[u] = fmaf(vv[u][j].z, z[j].z, d[u]);
+                d[u] = fmaf(vv[u][j].w, z[j].w, d[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u < k ? t0 + u : k - 1;
+            const float4 *b = reinterpret_cast<const float4 *>(B + (size_t)t * ld);
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int chunk = j * 16 + lane;
+                vv[u][j] = b[chunk < nchunks ? chunk : nchunks - 1];
+            }
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = group_sum<16>(d[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (t0 + u < k) {
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    acc[j].x = fmaf(d[u], vv[u][j].x, acc[j].x);
+                    acc[j].y = fmaf(d[u], vv[u][j].y, acc[j].y);
+                    acc[j].z = fmaf(d[u], vv[u][j].z, acc[j].z);
+                    acc[j].w = fmaf(d[u], vv[u][j].w, acc[j].w);
+                }
             }
         }
     }
