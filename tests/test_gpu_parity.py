@@ -600,6 +600,23 @@ def test_error_reporting(hip):
         ctx.run(1)
     with pytest.raises(LmcmaError, match="nz must be 1"):
         ctx.set_grid(np.zeros((2, 4, 4), dtype=np.uint8))
+    with pytest.raises(LmcmaError, match="nz must be 1"):
+        ctx.set_grid_from_occupancy(np.zeros((2, 4, 4), dtype=np.uint8))
+    with pytest.raises(LmcmaError, match="d_min"):
+        ctx.set_grid_from_occupancy(np.zeros((4, 4), dtype=np.uint8), d_min=0.0)
+    with pytest.raises(LmcmaError, match="1024"):
+        ctx.set_grid_from_occupancy(np.zeros((2, 1025), dtype=np.uint8))
+    with pytest.raises(ValueError):
+        ctx.set_cov_factor(np.eye(5))
+    with pytest.raises(LmcmaError, match="not finite"):
+        ctx.set_cov_factor(np.full((64, 64), np.nan))
+    assert 0.0 < ctx.timing_event_overhead(64) < 1.0   # milliseconds per empty event bracket
+    ctx.close()
+    # normals drawn by the caller carry the factor already: the device does not take one
+    ctx = hip.HipContext(64, 16, 4, z_source=hip.Z_HOST, cost_source=hip.COST_EXTERNAL)
+    with pytest.raises(LmcmaError, match="z_source HOST"):
+        ctx.set_cov_factor(np.eye(64))
+    ctx.set_cov_factor(None)
     ctx.close()
 
 
