@@ -100,6 +100,7 @@ struct lmcma_hip_ctx {
     uint32_t *key_buf[2] = {nullptr, nullptr};
     float *best = nullptr;                      // a shard: lowest cost of the population
     bool ranked_local_only = false;             // the last ranking covered the local candidates only
+    bool pre_done = false;   // the first part of this generation's update ran with a ranking launch
     int psr_parts_n = 0;   // per-workgroup success-rule counts the last ranking left at the head of `keys`
     int32_t *perm = nullptr;
     uint64_t *keys = nullptr;
@@ -319,7 +320,7 @@ UpdateArgs update_args(const lmcma_hip_ctx *c, const double *partials, int n_par
 
 // with_recombine: the ranking launch also leaves the elite partial sums of the local rows
 // in block_partials (*rows_out rows); only populations ranked by counting
-int do_select(lmcma_hip_ctx *c, bool with_recombine, int *rows_out)
+int do_select(lmcma_hip_ctx *c, bool with_recombine, int *rows_out, bool with_pre = false)
 {
     Timed tm(c, LMCMA_K_SELECT);
     // the two sorted-cost buffers alternate: this generation's list is written beside last one's
@@ -337,8 +338,11 @@ int do_select(lmcma_hip_ctx *c, bool with_recombine, int *rows_out)
     a.prev_sorted = c->sorted_buf[c->parity ^ 1];
     a.psr_accum = c->psr_accum;
     a.rc = recombine ? &rc : nullptr;
+    const UpdateArgs pre = update_args(c, nullptr, 0, false);
+    a.pre = (with_pre && c->opt_ready && !c->pre_done) ? &pre : nullptr;
     SelectResult res{};
     HIP_TRY(launch_select(c->stream, a, &res));
+    if (res.pre_done) c->pre_done = true;
     c->psr_parts_n = res.psr_parts;
     c->ranked_local_only = false;
     if (rows_out) *rows_out = res.partial_rows;
@@ -380,7 +384,15 @@ int do_recombine_final(lmcma_hip_ctx *c, int rows, bool with_scalars)
 int do_update(lmcma_hip_ctx *c, const double *partials, int n_partials, bool rows_with_scalars)
 {
     Timed tm(c, LMCMA_K_UPDATE);
-    HIP_TRY(launch_update(c->stream, update_args(c, partials, n_partials, rows_with_scalars)));
+    const UpdateArgs a = update_args(c, partials, n_partials, rows_with_scalars);
+    if (update_is_split(a.N, a.m)) {
+        // the part that does not depend on this generation's costs, unless a ranking launch carried it
+        if (!c->pre_done) HIP_TRY(launch_update_pre(c->stream, a));
+        c->pre_done = false;
+        HIP_TRY(launch_update_post(c->stream, a));
+        return LMCMA_HIP_OK;
+    }
+    HIP_TRY(launch_update(c->stream, a));
     return LMCMA_HIP_OK;
 }
 
@@ -394,7 +406,7 @@ int one_generation(lmcma_hip_ctx *c)
         if ((rc = do_evaluate(c)) != LMCMA_HIP_OK) return rc;
     }
     int rows = 0;
-    if ((rc = do_select(c, true, &rows)) != LMCMA_HIP_OK) return rc;
+    if ((rc = do_select(c, true, &rows, true)) != LMCMA_HIP_OK) return rc;
     if (rows > 0) return do_update(c, c->block_partials, rows, false);
     if ((rc = do_recombine(c)) != LMCMA_HIP_OK) return rc;
     return do_update(c, c->block_partials, recombine_num_blocks(c->mu), false);
@@ -989,6 +1001,7 @@ int lmcma_hip_opt_init(lmcma_hip_ctx *c, const double *xmean0, double sigma0)
     HIP_TRY(hipStreamSynchronize(nullptr));  // the fills above: done before the context's stream is used
     c->sigma0 = sigma0;
     c->opt_ready = true;
+    c->pre_done = false;
     c->have_state = true;
     return LMCMA_HIP_OK;
 }
@@ -997,6 +1010,7 @@ int lmcma_hip_opt_reset(lmcma_hip_ctx *c)
 {
     CTX_TRY(c);
     if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
+    c->pre_done = false;
     hipLaunchKernelGGL(k_opt_reset, dim3(1), dim3(256), 0, c->stream, c->opt, c->sc, c->xmean0, c->sigma0,
                        c->xmean, c->xmean_f, c->pc, c->N, c->ld);
     HIP_TRY(hipGetLastError());
@@ -1075,7 +1089,12 @@ int lmcma_hip_phase_local(lmcma_hip_ctx *c)
     a.keys_ws = c->keys;
     a.sorted_cost = c->cost_all + c->first;
     a.perm = c->local_perm;
-    HIP_TRY(launch_select(c->stream, a, nullptr));
+    // (the first part of the update rides along with this launch when it can)
+    const UpdateArgs pre = update_args(c, nullptr, 0, false);
+    a.pre = c->pre_done ? nullptr : &pre;
+    SelectResult res{};
+    HIP_TRY(launch_select(c->stream, a, &res));
+    if (res.pre_done) c->pre_done = true;
     return LMCMA_HIP_OK;
 }
 
@@ -1111,7 +1130,7 @@ int lmcma_hip_phase_rank(lmcma_hip_ctx *c)
         }
         return do_recombine_final(c, rows, true);
     }
-    int rc = do_select(c, true, &rows);
+    int rc = do_select(c, true, &rows, true);
     if (rc != LMCMA_HIP_OK) return rc;
     if (rows > 0) return do_recombine_final(c, rows, true);
     rc = do_recombine(c);

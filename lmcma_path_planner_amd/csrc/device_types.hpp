@@ -110,6 +110,7 @@ struct RecombineArgs {
 // workgroup in the first words of keys_ws (SelectResult::psr_parts of them).
 // rc (counting path only): the same launch adds the elite rows of the local candidates
 // into SelectResult::partial_rows rows of rc->block_partials.
+struct UpdateArgs;
 struct SelectArgs {
     const float *cost_all;
     int lambda;
@@ -120,10 +121,14 @@ struct SelectArgs {
     const float *prev_sorted;
     unsigned long long *psr_accum;
     const RecombineArgs *rc;
+    // the first part of the update (update_pre_body) may ride along as one more workgroup of
+    // the counting launch; SelectResult::pre_done tells whether it did
+    const UpdateArgs *pre;
 };
 struct SelectResult {
     int partial_rows;   // rows of block_partials written (0: recombination not done)
     int psr_parts;      // per-workgroup success-rule counts left in keys_ws (0: see psr_accum)
+    int pre_done;
 };
 hipError_t launch_select(hipStream_t s, const SelectArgs &a, SelectResult *res);
 hipError_t launch_select_sort(hipStream_t s, const SelectArgs &a);
@@ -199,5 +204,11 @@ struct UpdateArgs {
     float *V_f, *B_f;           // [m][ld] in iterator order, B = M^(k-1-t) nj pc
 };
 hipError_t launch_update(hipStream_t s, const UpdateArgs &a);
+// The update in two launches (update_body.hpp): vectors that do not depend on this generation's
+// costs, then the rest.  update_is_split: the sizes the two-part kernels cover.
+bool update_is_split(int N, int m);
+int update_pre_threads(int m);  // threads of the first part that do vector work
+hipError_t launch_update_pre(hipStream_t s, const UpdateArgs &a);
+hipError_t launch_update_post(hipStream_t s, const UpdateArgs &a);
 
 }  // namespace lmcma

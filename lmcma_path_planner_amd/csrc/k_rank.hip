@@ -43,6 +43,9 @@ struct RankArgs {
     int weights_in_lds;
     double *block_partials;      // [workgroups holding local candidates][N]
     int first_block;
+    // PRE_EMAX > 0: the last workgroup of the grid runs the first part of the update instead
+    UpdateArgs pre;
+    int pre_threads;
 };
 
 __device__ __forceinline__ uint32_t row16_sum_u32(uint32_t v)
@@ -74,10 +77,18 @@ size_t rank_lds_bytes(int TB, int lambda, int N, int mu, bool psr, bool recombin
 #define RANK_STAMP(i)
 #endif
 
-template <int TB>
+template <int TB, int PRE_EMAX>
 __global__ __launch_bounds__(TB) void k_rank(const RankArgs r)
 {
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+    if (PRE_EMAX > 0) {
+        // The vectors of the direction store that do not depend on this generation's costs are
+        // rebuilt here, on a CU the ranking leaves idle, instead of after the ranking.
+        if (blockIdx.x == gridDim.x - 1) {
+            update_pre_body<(PRE_EMAX > 0 ? PRE_EMAX : 8)>(r.pre, s_dyn, r.pre_threads);
+            return;
+        }
+    }
     constexpr int CPB = TB / 16;  // candidates per workgroup
     const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
     const int lambda = r.lambda, N = r.N;
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(TB) void k_rank(const RankArgs r)
     }
 #ifdef LMCMA_DIAG
     RANK_STAMP(4);
-    if (tid == 0 && blockIdx.x == gridDim.x - 1)
+    if (tid == 0 && blockIdx.x == gridDim.x - 1 - (PRE_EMAX > 0 ? 1 : 0))
         for (int q = 0; q < 5; ++q) g_update_stamps[8 + q] = st[q];
 #endif
 }
@@ -499,18 +510,30 @@ hipError_t launch_rank_merge_t(hipStream_t s, const RankMergeArgs &r, int blocks
     return hipGetLastError();
 }
 
-template <int TB>
-hipError_t launch_rank_t(hipStream_t s, const RankArgs &r, int blocks, size_t lds)
+template <int TB, int PRE_EMAX>
+hipError_t launch_rank_tp(hipStream_t s, const RankArgs &r, int blocks, size_t lds)
 {
     static size_t configured = 48 * 1024;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rank<TB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rank<TB, PRE_EMAX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL((k_rank<TB>), dim3(blocks), dim3(TB), lds, s, r);
+    hipLaunchKernelGGL((k_rank<TB, PRE_EMAX>), dim3(blocks + (PRE_EMAX > 0 ? 1 : 0)), dim3(TB), lds, s, r);
     return hipGetLastError();
+}
+
+// pre_emax: 0, or the register tile (8 / 16 / 32 coordinates per lane) of the update part riding along
+template <int TB>
+hipError_t launch_rank_t(hipStream_t s, const RankArgs &r, int blocks, size_t lds, int pre_emax)
+{
+    if (TB <= 512) {  // the update part needs the registers of a workgroup of at most 512 threads
+        if (pre_emax == 8) return launch_rank_tp<TB, (TB <= 512 ? 8 : 0)>(s, r, blocks, lds);
+        if (pre_emax == 16) return launch_rank_tp<TB, (TB <= 512 ? 16 : 0)>(s, r, blocks, lds);
+        if (pre_emax == 32) return launch_rank_tp<TB, (TB <= 512 ? 32 : 0)>(s, r, blocks, lds);
+    }
+    return launch_rank_tp<TB, 0>(s, r, blocks, lds);
 }
 
 }  // namespace
@@ -612,11 +635,23 @@ hipError_t launch_select(hipStream_t s, const SelectArgs &a, SelectResult *res)
     size_t lds = rank_lds_bytes(TB, lambda, r.N, r.mu, psr, rc != nullptr, true);
     r.weights_in_lds = rc && lds <= 150 * 1024;
     if (!r.weights_in_lds) lds = rank_lds_bytes(TB, lambda, r.N, r.mu, psr, rc != nullptr, false);
+    // The first part of the update as one more workgroup: when the ranking leaves CUs idle
+    // (at most one workgroup per CU) and its workgroup is large enough for the vectors.
+    int pre_emax = 0;
+    if (a.pre && update_is_split(a.pre->N, a.pre->m) && blocks < 256 && TB <= 512 &&
+        update_pre_threads(a.pre->m) <= TB) {
+        r.pre = *a.pre;
+        r.pre_threads = update_pre_threads(a.pre->m);
+        const int emax = (a.pre->N + 15) / 16;
+        pre_emax = emax <= 8 ? 8 : emax <= 16 ? 16 : 32;
+        lds = std::max(lds, update_pre_lds_doubles(a.pre->N, a.pre->m) * sizeof(double));
+    }
     hipError_t e;
-    if (TB == 256) e = launch_rank_t<256>(s, r, blocks, lds);
-    else if (TB == 512) e = launch_rank_t<512>(s, r, blocks, lds);
-    else e = launch_rank_t<1024>(s, r, blocks, lds);
+    if (TB == 256) e = launch_rank_t<256>(s, r, blocks, lds, pre_emax);
+    else if (TB == 512) e = launch_rank_t<512>(s, r, blocks, lds, pre_emax);
+    else e = launch_rank_t<1024>(s, r, blocks, lds, pre_emax);
     out.partial_rows = rows;
+    out.pre_done = pre_emax > 0;
     out.psr_parts = opt ? blocks : 0;
     if (res) *res = out;
     return e;

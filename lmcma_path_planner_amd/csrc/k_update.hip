@@ -94,6 +94,20 @@ __global__ __launch_bounds__(update_block_threads(TB)) void k_update(const Updat
     update_body<EMAX, V_LDS>(a, s_dyn, TB, update_row_threads(TB));
 }
 
+template <int TB, int EMAX>
+__global__ __launch_bounds__(TB) void k_update_pre(const UpdateArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+    update_pre_body<EMAX>(a, s_dyn, TB);
+}
+
+template <int TB, int EMAX>
+__global__ __launch_bounds__(update_block_threads(TB)) void k_update_post(const UpdateArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+    update_post_body<EMAX>(a, s_dyn, TB, update_row_threads(TB));
+}
+
 }  // namespace
 
 #ifdef LMCMA_DIAG
@@ -122,6 +136,14 @@ static bool update_fits_lds(int N, int m)
 
 // threads that add the partial rows in the update (the order of that sum depends on it)
 int update_threads(int N, int m) { return update_fits_lds(N, m) ? update_row_threads(threads_for_vectors(m)) : 1024; }
+
+bool update_is_split(int N, int m)
+{
+    static const bool off = getenv("LMCMA_HIP_UPDATE_ONE_KERNEL") != nullptr;
+    return !off && m >= 1 && m <= LMCMA_HIP_MAX_VECTORS && N >= 1 && N <= 512 && update_fits_lds(N, m);
+}
+
+int update_pre_threads(int m) { return threads_for_vectors(m); }
 
 int recombine_num_blocks(int mu)
 {
@@ -165,6 +187,62 @@ static hipError_t launch_update_t(hipStream_t s, const UpdateArgs &a)
     hipLaunchKernelGGL((k_update<TB, EMAX, V_LDS>), dim3(1), dim3(update_block_threads(TB)), lds, s, a);
     return hipGetLastError();
 }
+
+template <int TB, int EMAX>
+static hipError_t launch_pre_t(hipStream_t s, const UpdateArgs &a)
+{
+    const size_t lds = update_pre_lds_doubles(a.N, a.m) * sizeof(double);
+    static size_t configured = 48 * 1024;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_update_pre<TB, EMAX>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL((k_update_pre<TB, EMAX>), dim3(1), dim3(TB), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int TB, int EMAX>
+static hipError_t launch_post_t(hipStream_t s, const UpdateArgs &a)
+{
+    const size_t lds = update_post_lds_doubles(a.N, a.m, update_row_threads(TB)) * sizeof(double);
+    static size_t configured = 48 * 1024;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_update_post<TB, EMAX>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL((k_update_post<TB, EMAX>), dim3(1), dim3(update_block_threads(TB)), lds, s, a);
+    return hipGetLastError();
+}
+
+#define LMCMA_UPD_SPLIT(FN, TB)                              \
+    do {                                                     \
+        if (emax <= 8) return FN<TB, 8>(s, a);               \
+        if (emax <= 16) return FN<TB, 16>(s, a);             \
+        return FN<TB, 32>(s, a);                             \
+    } while (0)
+
+hipError_t launch_update_pre(hipStream_t s, const UpdateArgs &a)
+{
+    if (!update_is_split(a.N, a.m)) return hipErrorInvalidValue;
+    const int threads = threads_for_vectors(a.m), emax = (a.N + 15) / 16;
+    if (threads == 256) LMCMA_UPD_SPLIT(launch_pre_t, 256);
+    if (threads == 512) LMCMA_UPD_SPLIT(launch_pre_t, 512);
+    LMCMA_UPD_SPLIT(launch_pre_t, 1024);
+}
+
+hipError_t launch_update_post(hipStream_t s, const UpdateArgs &a)
+{
+    if (!update_is_split(a.N, a.m) || a.n_partials < 1) return hipErrorInvalidValue;
+    const int threads = threads_for_vectors(a.m), emax = (a.N + 15) / 16;
+    if (threads == 256) LMCMA_UPD_SPLIT(launch_post_t, 256);
+    if (threads == 512) LMCMA_UPD_SPLIT(launch_post_t, 512);
+    LMCMA_UPD_SPLIT(launch_post_t, 1024);
+}
+#undef LMCMA_UPD_SPLIT
 
 hipError_t launch_update(hipStream_t s, const UpdateArgs &a)
 {

@@ -558,4 +558,423 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, 
     LMCMA_STAMP(5);
 }
 
+// ---- the update in two parts ----------------------------------------------------------
+// Of the vectors rebuilt in a generation only the newest one (the last position of the
+// time-ordered list, L/:365-366) starts from the new evolution path, and with it from this
+// generation's costs.  The others start from paths stored in earlier generations and pass
+// through transforms of vectors before them in the list: their rebuild needs nothing of
+// this generation and can run beside its sampling and ranking (update_pre_body, one
+// workgroup, e.g. an extra workgroup of the ranking launch).  What remains after the ranking
+// (update_post_body) is the mean, the path, the step size, and the newest vector alone
+// walking through the finished ones: no barrier per step.
+//
+// Both parts derive the slot bookkeeping (L/:331-364) from the tables of the last update;
+// the second part writes the new tables.  The first part writes v_arr, nj and lj of the
+// slots it rebuilds, nothing the sampling or ranking kernels read.
+
+struct SlotPlan {
+    int t_reg, vec_reg;  // the new tables, one entry per lane
+    int imin, isz, newidx;
+    int pos;             // position of this group's slot in the new list, -1: not in use
+};
+
+// t_reg / vec_reg: entry wl of the old tables in lane wl (m <= 64); grp: the slot of this 16-lane group
+__device__ __forceinline__ SlotPlan slot_plan(int t_reg, int vec_reg, int itr, int m, int tid)
+{
+    const int wl = tid & 63, grp = tid >> 4;
+    int imin = 1;
+    if (itr < m) {
+        if (wl == itr) t_reg = itr;
+    } else if (m > 1) {
+        const int vt = __shfl(vec_reg, t_reg, 64);  // vec[t[j]] in lane j
+        const int vnext = __shfl_down(vt, 1, 64);
+        const int gap = (wl < m - 1) ? vnext - vt : 0x7fffffff;
+        const int dmin = wave_min_i32(gap);
+        // first position with the smallest gap (the reference replaces on strict "<" only)
+        imin = __ffsll((unsigned long long)__ballot(gap == dmin));
+        if (dmin >= m) imin = 0;  // maxsteps = nvectors (L/:267)
+        if (imin != m - 1) {
+            const int sav = __shfl(t_reg, imin, 64);
+            const int nxt = __shfl_down(t_reg, 1, 64);
+            if (wl >= imin && wl < m - 1) t_reg = nxt;
+            if (wl == m - 1) t_reg = sav;
+        }
+    } else {
+        imin = 0;
+    }
+    const int isz = itr + 1 < m ? itr + 1 : m;
+    const int newidx = __shfl(t_reg, isz - 1, 64);
+    if (wl == newidx) vec_reg = itr;
+    if (imin == 1) imin = 0;  // L/:373-374
+    int pos = -1;
+    const int g0 = (tid >> 6) << 2;  // first group of this wave
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned long long hit = __ballot(wl < isz && t_reg == g0 + q);
+        if ((grp & 3) == q && hit != 0ull) pos = __ffsll(hit) - 1;
+    }
+    return {t_reg, vec_reg, imin, isz, newidx, pos};
+}
+
+// LDS doubles of the two parts (vectors by position, padded rows; norms and lj by position)
+__host__ __device__ inline size_t update_pre_lds_doubles(int N, int m)
+{
+    const size_t np = N <= 128 ? 128 : N <= 256 ? 256 : 512;
+    return (size_t)m * np + 2 * LMCMA_HIP_MAX_VECTORS;
+}
+
+// First part.  T >= 16 m threads work (the workgroup may be larger: the others only meet the
+// barriers).  EMAX >= N / 16.
+template <int EMAX>
+__device__ __forceinline__ void update_pre_body(const UpdateArgs &a, double *s_dyn, int T)
+{
+    const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
+    const int N = a.N, m = a.m;
+    const OptScalars &o = *a.opt;
+    const double c1 = o.c1, K = o.K;
+    const int itr = o.itr;
+    const bool worker = tid < T;
+    constexpr int NP = EMAX * 16;
+    double *s_v = s_dyn;                         // [m][NP] by position, zero beyond N
+    double *s_nv = s_v + (size_t)m * NP;         // [64] |v_i|^2
+    double *s_ljp = s_nv + LMCMA_HIP_MAX_VECTORS;  // [64] lj of the untouched vectors
+
+    int t_reg = 0, vec_reg = 0;
+    if (wl < m) {
+        t_reg = a.t[wl];
+        vec_reg = a.vec[wl];
+    }
+    const bool has_slot = worker && grp < m;
+    const int slot = has_slot ? grp : 0;
+    const double lj_old = a.lj[slot];
+    double vold[EMAX], pcq[EMAX];
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) pcq[e] = vold[e] = 0.0;
+    if (worker) {
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const int n = e * 16 + lane;
+            const size_t at = (size_t)slot * N + (n < N ? n : N - 1);
+            pcq[e] = a.pc_arr[at];
+            vold[e] = a.v_arr[at];
+        }
+    }
+    asm volatile("" ::: "memory");
+    const SlotPlan sp = slot_plan(t_reg, vec_reg, itr, m, tid);
+    const int imin = sp.imin, isz = sp.isz, pos = sp.pos;
+    const bool own = has_slot && pos >= 0;
+    const bool newest = own && slot == sp.newidx;
+    const bool rebuild = own && pos >= imin && !newest;
+    const double sq = sqrt(1 - c1), ratio = c1 / (1 - c1);
+
+    double av[EMAX];
+    double aa = 0.0;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        const int n = e * 16 + lane;
+        const bool in = own && n < N;
+        av[e] = in ? (rebuild ? pcq[e] : vold[e]) : 0.0;  // L/:376-377: a rebuilt vector starts from its path
+        aa += av[e] * av[e];
+    }
+    aa = row16_sum(aa);
+    if (own && !rebuild && !newest) {
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) s_v[(size_t)pos * NP + e * 16 + lane] = av[e];
+        if (lane == 0) {
+            s_nv[pos] = aa;
+            s_ljp[pos] = lj_old;
+        }
+    }
+    __syncthreads();
+    // vector i is final once it has received T_0 .. T_{i-1}; the last one rebuilt here is at
+    // position isz - 2 and needs transforms up to isz - 3
+    for (int i = 0; i < isz - 2; ++i) {
+        const bool fresh = i >= imin;  // same for every thread
+        if (fresh) {
+            if (pos == i && rebuild) {
+#pragma unroll
+                for (int e = 0; e < EMAX; ++e) s_v[(size_t)i * NP + e * 16 + lane] = av[e];
+                if (lane == 0) s_nv[i] = aa;
+            }
+            __syncthreads();
+        }
+        if (rebuild && pos > i) {
+            const double *vi = s_v + (size_t)i * NP;
+            double vv[EMAX];
+            double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+            for (int e = 0; e < EMAX; e += 2) {
+                vv[e] = vi[e * 16 + lane];
+                vv[e + 1] = vi[(e + 1) * 16 + lane];
+                p0 += vv[e] * av[e];
+                p1 += vv[e + 1] * av[e + 1];
+            }
+            const double nvi = s_nv[i];
+            const double lji = fresh ? lj_of(nvi, sq, ratio) : s_ljp[i];
+            const double p = row16_sum(p0 + p1);
+            const double d = lji * p;
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) av[e] = K * av[e] - d * vv[e];
+            aa = K * K * aa - 2.0 * K * d * p + d * d * nvi;
+        }
+    }
+    if (rebuild) {
+        // L/:386-389
+        if (lane == 0) {
+            a.nj[slot] = (sq / aa) * (sqrt(1 + ratio * aa) - 1);
+            a.lj[slot] = lj_of(aa, sq, ratio);
+        }
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const int n = e * 16 + lane;
+            if (n < N) a.v_arr[(size_t)slot * N + n] = av[e];
+        }
+    }
+}
+
+// LDS doubles of the second part when TR threads read the partial rows
+__host__ __device__ inline size_t update_post_lds_doubles(int N, int m, int TR)
+{
+    const size_t np = N <= 128 ? 128 : N <= 256 ? 256 : 512;
+    return (size_t)m * np + np + row_sum_lds_doubles(N, TR) + LMCMA_HIP_MAX_VECTORS;
+}
+
+// Second part; thread roles as in update_body (T workers, TR row readers, the first wave
+// past the workers evaluates the step-size rule).
+template <int EMAX>
+__device__ __forceinline__ void update_post_body(const UpdateArgs &a, double *s_dyn, int T, int TR)
+{
+    constexpr bool KEEP_PC = EMAX <= 8;
+    const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
+    const int N = a.N, m = a.m, lambda = a.lambda;
+    OptScalars &o = *a.opt;
+    const double sigma = o.sigma, cc = o.cc, c1 = o.c1, K = o.K, Mfac = o.M;
+    const int itr = o.itr;
+    const bool worker = tid < T;
+    const int stid = (int)blockDim.x > T ? T : 0;
+    const bool swave = (tid >> 6) == (stid >> 6);
+    const double o_mueff = o.mueff, o_s = o.s, o_cs = o.cs, o_val_target = o.val_target, o_best_f = o.best_f;
+    const long long o_counteval = o.counteval;
+
+    constexpr int NP = EMAX * 16;
+    double *s_v = s_dyn;                         // [m][NP] finished vectors by position
+    double *s_pc = s_v + (size_t)m * NP;         // [NP] new evolution path
+    double *s_red = s_pc + NP;                   // [rg][N]
+    double *s_ljp = s_red + row_sum_lds_doubles(N, TR);  // [64] lj by position
+
+    LMCMA_STAMP(0);
+    int t_reg = 0, vec_reg = 0;
+    if (wl < m) {
+        t_reg = a.t[wl];
+        vec_reg = a.vec[wl];
+    }
+    const bool has_slot = worker && grp < m;
+    const int slot = has_slot ? grp : 0;
+    const double lj_old = a.lj[slot], nj_old = a.nj[slot];
+    double xold[2] = {0.0, 0.0}, pcold[2] = {0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int n = tid + q * T;
+        if (worker && n < N) {
+            xold[q] = a.xmean[n];
+            pcold[q] = a.pc[n];
+        }
+    }
+    uint32_t pp[16];
+    unsigned long long psr_lane = 0ull;
+    float best_in = 0.f;
+    if (swave) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int b = wl + 64 * u;
+            pp[u] = a.psr_parts[b < a.n_psr_parts ? b : 0];
+        }
+        if (a.scalars_in_rows) {
+            if (wl < a.n_partials) psr_lane = (unsigned long long)a.partials[(size_t)wl * a.partial_stride + N];
+            if (tid == stid) best_in = (float)a.partials[N + 1];
+        } else if (tid == stid) {
+            psr_lane = *a.psr_accum;
+            best_in = a.sorted_cost[0];
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) pp[u] = 0u;
+    }
+    double vold[EMAX], pcq[EMAX];
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) pcq[e] = vold[e] = 0.0;
+    if (worker) {
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const int n = e * 16 + lane;
+            const size_t at = (size_t)slot * N + (n < N ? n : N - 1);
+            pcq[e] = a.pc_arr[at];
+            vold[e] = a.v_arr[at];
+        }
+    }
+    RowSumBatch first_rows;
+    row_sums_begin(a.partials, a.n_partials, N, a.partial_stride, TR, first_rows);
+    asm volatile("" ::: "memory");
+    LMCMA_STAMP(1);
+
+    const SlotPlan sp = slot_plan(t_reg, vec_reg, itr, m, tid);
+    t_reg = sp.t_reg;
+    vec_reg = sp.vec_reg;
+    const int imin = sp.imin, isz = sp.isz, newidx = sp.newidx, pos = sp.pos;
+    const bool own = has_slot && pos >= 0;
+    const bool newest = own && slot == newidx;
+
+#pragma unroll
+    for (int u = 0; u < 16; ++u) psr_lane += (!a.scalars_in_rows && wl + 64 * u < a.n_psr_parts) ? pp[u] : 0u;
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) psr_lane += __shfl_xor(psr_lane, sft, 64);
+
+    const double pc_gain = sqrt(cc * (2 - cc) * o_mueff);
+    const double sq = sqrt(1 - c1), ratio = c1 / (1 - c1);
+
+    // L/:393-419 and the feedback bookkeeping, by one thread (see update_body)
+    double new_sigma = sigma, new_s = 0.0, new_best = 0.0, mk = 1.0;
+    long long new_counteval = 0;
+    if (tid == stid) {
+        new_s = o_s;
+        if (itr > 0) {
+            const long long cur_sum = (long long)lambda * (lambda - 1) / 2 + (long long)psr_lane;
+            const long long total = (long long)lambda * (2ll * lambda - 1);
+            const double mean_current = (double)cur_sum / lambda;
+            const double mean_previous = (double)(total - cur_sum) / lambda;
+            const double diffv = (mean_previous - mean_current) / lambda;
+            const double z1 = diffv - o_val_target;
+            new_s = (1 - o_cs) * new_s + o_cs * z1;
+            new_sigma = sigma * exp(new_s / 1.0);
+        }
+        const double best = (double)best_in;
+        new_counteval = o_counteval;
+        new_best = (best < o_best_f || new_counteval == 0) ? best : o_best_f;
+        new_counteval += lambda;
+        for (int q = 0; q < isz; ++q) mk *= Mfac;
+    }
+
+    // every vector but the newest is final: publish it by position
+    double av[EMAX];
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        const int n = e * 16 + lane;
+        const bool in = own && n < N;
+        if (!in) pcq[e] = 0.0;
+        av[e] = in ? vold[e] : 0.0;
+    }
+    if (own && !newest) {
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) s_v[(size_t)pos * NP + e * 16 + lane] = av[e];
+        if (lane == 0) s_ljp[pos] = lj_old;
+    }
+    row_sums_to_lds_t<true>(a.partials, a.n_partials, N, a.partial_stride, TR, s_red, first_rows);
+    __syncthreads();
+    LMCMA_STAMP(2);
+    // L/:316-329: new mean, evolution path
+    double xnew[2] = {0.0, 0.0}, pcn[2] = {0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int n = tid + q * T;
+        if (worker && n < N) {
+            xnew[q] = row_sums_total(s_red, N, n, row_sum_groups(N, TR));
+            pcn[q] = (1 - cc) * pcold[q] + pc_gain * (xnew[q] - xold[q]) / sigma;
+            s_pc[n] = pcn[q];
+        }
+    }
+    for (int n = N + tid; n < NP; n += (int)blockDim.x) s_pc[n] = 0.0;
+    __syncthreads();
+    LMCMA_STAMP(3);
+
+    // L/:375-390 with invAz (:449-463) for the newest vector: v = T_{k-2} ... T_0 pc
+    double nj_new = nj_old, lj_new = lj_old;
+    if (newest) {
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            av[e] = s_pc[e * 16 + lane];
+            pcq[e] = av[e];
+        }
+        for (int i = 0; i < isz - 1; ++i) {
+            const double *vi = s_v + (size_t)i * NP;
+            double vv[EMAX];
+            double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+            for (int e = 0; e < EMAX; e += 2) {
+                vv[e] = vi[e * 16 + lane];
+                vv[e + 1] = vi[(e + 1) * 16 + lane];
+                p0 += vv[e] * av[e];
+                p1 += vv[e + 1] * av[e + 1];
+            }
+            const double d = s_ljp[i] * row16_sum(p0 + p1);
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) av[e] = K * av[e] - d * vv[e];
+        }
+        double aa = 0.0;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) aa += av[e] * av[e];
+        aa = row16_sum(aa);
+        nj_new = (sq / aa) * (sqrt(1 + ratio * aa) - 1);
+        lj_new = lj_of(aa, sq, ratio);
+    }
+    if (!KEEP_PC) {
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) pcq[e] = 0.0;
+    }
+    LMCMA_STAMP(4);
+
+    // state back to memory, and the float images the sampling kernel reads, by position q:
+    // V_f[q] = v_q, B_f[q] = M^(k-1-q) nj_q pc_q
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int n = tid + q * T;
+        if (worker && n < N) {
+            a.xmean[n] = xnew[q];
+            a.pc[n] = pcn[q];
+        }
+        if (worker && n < a.ld) a.xmean_f[n] = (n < N) ? (float)xnew[q] : 0.f;
+    }
+    if (tid < m) {
+        a.t[tid] = t_reg;
+        a.vec[tid] = vec_reg;
+        if (tid < isz) a.iterator[tid] = t_reg;
+    }
+    if (own) {
+        if (newest && lane == 0) {
+            a.nj[slot] = nj_new;
+            a.lj[slot] = lj_new;
+        }
+        double coef = nj_new;
+        for (int e = 0; e < isz - 1 - pos; ++e) coef *= Mfac;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const int n = e * 16 + lane;
+            double pv = pcq[e];
+            if (!KEEP_PC) pv = n < N ? (newest ? s_pc[n] : a.pc_arr[(size_t)slot * N + n]) : 0.0;
+            if (n < N && newest) {
+                a.pc_arr[(size_t)slot * N + n] = pv;
+                a.v_arr[(size_t)slot * N + n] = av[e];
+            }
+            if (n < a.ld) {
+                a.V_f[(size_t)pos * a.ld + n] = (n < N) ? (float)av[e] : 0.f;
+                a.B_f[(size_t)pos * a.ld + n] = (n < N) ? (float)(coef * pv) : 0.f;
+            }
+        }
+    }
+    if (tid == stid) {
+        o.s = new_s;
+        o.sigma = new_sigma;
+        o.best_f = new_best;
+        o.counteval = new_counteval;
+        o.itr = itr + 1;
+        o.iterator_sz = isz;
+        o.imin_last = imin;
+        a.sc->sigma = (float)new_sigma;
+        a.sc->mk = (float)mk;
+        a.sc->k = isz;
+        a.sc->generation = (uint32_t)(itr + 1);
+        *a.psr_accum = 0ull;
+    }
+    LMCMA_STAMP(5);
+}
+
 }  // namespace lmcma
