@@ -894,20 +894,32 @@ __device__ __forceinline__ void update_post_body(const UpdateArgs &a, double *s_
             av[e] = s_pc[e * 16 + lane];
             pcq[e] = av[e];
         }
+        // the steps depend on each other through av only: the next vector and its lj are read
+        // from LDS while this step's sums are under way
+        double vv[EMAX];
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) vv[e] = s_v[e * 16 + lane];
+        double lji = s_ljp[0];
         for (int i = 0; i < isz - 1; ++i) {
-            const double *vi = s_v + (size_t)i * NP;
-            double vv[EMAX];
+            const int nx = i + 1 < isz - 1 ? i + 1 : i;
+            const double *vn = s_v + (size_t)nx * NP;
+            double vnext[EMAX];
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) vnext[e] = vn[e * 16 + lane];
+            const double ljn = s_ljp[nx];
             double p0 = 0.0, p1 = 0.0;
 #pragma unroll
             for (int e = 0; e < EMAX; e += 2) {
-                vv[e] = vi[e * 16 + lane];
-                vv[e + 1] = vi[(e + 1) * 16 + lane];
                 p0 += vv[e] * av[e];
                 p1 += vv[e + 1] * av[e + 1];
             }
-            const double d = s_ljp[i] * row16_sum(p0 + p1);
+            const double d = lji * row16_sum(p0 + p1);
 #pragma unroll
-            for (int e = 0; e < EMAX; ++e) av[e] = K * av[e] - d * vv[e];
+            for (int e = 0; e < EMAX; ++e) {
+                av[e] = K * av[e] - d * vv[e];
+                vv[e] = vnext[e];
+            }
+            lji = ljn;
         }
         double aa = 0.0;
 #pragma unroll
