@@ -629,11 +629,14 @@ template <int EMAX>
 __device__ __forceinline__ void update_pre_body(const UpdateArgs &a, double *s_dyn, int T)
 {
     const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
+    // Waves without vector work leave at once: a wave that has ended no longer counts at the
+    // workgroup's barriers, which the loop below crosses once per step.
+    if (tid >= T) return;
     const int N = a.N, m = a.m;
     const OptScalars &o = *a.opt;
     const double c1 = o.c1, K = o.K;
     const int itr = o.itr;
-    const bool worker = tid < T;
+    const bool worker = true;
     constexpr int NP = EMAX * 16;
     double *s_v = s_dyn;                         // [m][NP] by position, zero beyond N
     double *s_nv = s_v + (size_t)m * NP;         // [64] |v_i|^2
