@@ -528,11 +528,10 @@ hipError_t launch_rank_tp(hipStream_t s, const RankArgs &r, int blocks, size_t l
 template <int TB>
 hipError_t launch_rank_t(hipStream_t s, const RankArgs &r, int blocks, size_t lds, int pre_emax)
 {
-    if (TB <= 512) {  // the update part needs the registers of a workgroup of at most 512 threads
-        if (pre_emax == 8) return launch_rank_tp<TB, (TB <= 512 ? 8 : 0)>(s, r, blocks, lds);
-        if (pre_emax == 16) return launch_rank_tp<TB, (TB <= 512 ? 16 : 0)>(s, r, blocks, lds);
-        if (pre_emax == 32) return launch_rank_tp<TB, (TB <= 512 ? 32 : 0)>(s, r, blocks, lds);
-    }
+    // the update part must fit the registers the workgroup size leaves per lane
+    if (pre_emax == 8) return launch_rank_tp<TB, 8>(s, r, blocks, lds);
+    if (pre_emax == 16) return launch_rank_tp<TB, 16>(s, r, blocks, lds);
+    if (pre_emax == 32 && TB <= 512) return launch_rank_tp<TB, (TB <= 512 ? 32 : 0)>(s, r, blocks, lds);
     return launch_rank_tp<TB, 0>(s, r, blocks, lds);
 }
 
@@ -638,8 +637,8 @@ hipError_t launch_select(hipStream_t s, const SelectArgs &a, SelectResult *res)
     // The first part of the update as one more workgroup: when the ranking leaves CUs idle
     // (at most one workgroup per CU) and its workgroup is large enough for the vectors.
     int pre_emax = 0;
-    if (a.pre && update_is_split(a.pre->N, a.pre->m) && blocks < 256 && TB <= 512 &&
-        update_pre_threads(a.pre->m) <= TB) {
+    if (a.pre && update_is_split(a.pre->N, a.pre->m) && blocks <= 256 && update_pre_threads(a.pre->m) <= TB &&
+        (TB <= 512 || a.pre->N <= 256)) {
         r.pre = *a.pre;
         r.pre_threads = update_pre_threads(a.pre->m);
         const int emax = (a.pre->N + 15) / 16;
