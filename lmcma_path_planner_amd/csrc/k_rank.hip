@@ -530,8 +530,8 @@ hipError_t launch_rank_t(hipStream_t s, const RankArgs &r, int blocks, size_t ld
 {
     // the update part must fit the registers the workgroup size leaves per lane
     if (pre_emax == 8) return launch_rank_tp<TB, 8>(s, r, blocks, lds);
+    if (pre_emax == 12) return launch_rank_tp<TB, 12>(s, r, blocks, lds);
     if (pre_emax == 16) return launch_rank_tp<TB, 16>(s, r, blocks, lds);
-    if (pre_emax == 32 && TB <= 512) return launch_rank_tp<TB, (TB <= 512 ? 32 : 0)>(s, r, blocks, lds);
     return launch_rank_tp<TB, 0>(s, r, blocks, lds);
 }
 
@@ -638,11 +638,10 @@ hipError_t launch_select(hipStream_t s, const SelectArgs &a, SelectResult *res)
     // (at most one workgroup per CU) and its workgroup is large enough for the vectors.
     int pre_emax = 0;
     if (a.pre && update_is_split(a.pre->N, a.pre->m) && blocks <= 256 && update_pre_threads(a.pre->m) <= TB &&
-        (TB <= 512 || a.pre->N <= 256)) {
+        a.pre->N <= 256) {  // longer vectors: the stand-alone kernel (fewer variants of this one)
         r.pre = *a.pre;
         r.pre_threads = update_pre_threads(a.pre->m);
-        const int emax = (a.pre->N + 15) / 16;
-        pre_emax = emax <= 8 ? 8 : emax <= 16 ? 16 : 32;
+        pre_emax = update_emax(a.pre->N);
         lds = std::max(lds, update_pre_lds_doubles(a.pre->N, a.pre->m) * sizeof(double));
     }
     hipError_t e;

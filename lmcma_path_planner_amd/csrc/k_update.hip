@@ -223,15 +223,18 @@ static hipError_t launch_post_t(hipStream_t s, const UpdateArgs &a)
 
 #define LMCMA_UPD_SPLIT(FN, TB)                              \
     do {                                                     \
-        if (emax <= 8) return FN<TB, 8>(s, a);               \
-        if (emax <= 16) return FN<TB, 16>(s, a);             \
+        if (emax == 8) return FN<TB, 8>(s, a);               \
+        if (emax == 12) return FN<TB, 12>(s, a);             \
+        if (emax == 16) return FN<TB, 16>(s, a);             \
+        if (emax == 20) return FN<TB, 20>(s, a);             \
+        if (emax == 24) return FN<TB, 24>(s, a);             \
         return FN<TB, 32>(s, a);                             \
     } while (0)
 
 hipError_t launch_update_pre(hipStream_t s, const UpdateArgs &a)
 {
     if (!update_is_split(a.N, a.m)) return hipErrorInvalidValue;
-    const int threads = threads_for_vectors(a.m), emax = (a.N + 15) / 16;
+    const int threads = threads_for_vectors(a.m), emax = update_emax(a.N);
     if (threads == 256) LMCMA_UPD_SPLIT(launch_pre_t, 256);
     if (threads == 512) LMCMA_UPD_SPLIT(launch_pre_t, 512);
     LMCMA_UPD_SPLIT(launch_pre_t, 1024);
@@ -240,7 +243,7 @@ hipError_t launch_update_pre(hipStream_t s, const UpdateArgs &a)
 hipError_t launch_update_post(hipStream_t s, const UpdateArgs &a)
 {
     if (!update_is_split(a.N, a.m) || a.n_partials < 1) return hipErrorInvalidValue;
-    const int threads = threads_for_vectors(a.m), emax = (a.N + 15) / 16;
+    const int threads = threads_for_vectors(a.m), emax = update_emax(a.N);
     if (threads == 256) LMCMA_UPD_SPLIT(launch_post_t, 256);
     if (threads == 512) LMCMA_UPD_SPLIT(launch_post_t, 512);
     LMCMA_UPD_SPLIT(launch_post_t, 1024);
@@ -252,12 +255,15 @@ hipError_t launch_update(hipStream_t s, const UpdateArgs &a)
     if (a.m < 1 || a.m > LMCMA_HIP_MAX_VECTORS || a.N < 1 || a.N > 512 || a.n_partials < 1)
         return hipErrorInvalidValue;
     const int threads = threads_for_vectors(a.m);
-    const int emax = (a.N + 15) / 16;
+    const int emax = update_emax(a.N);
     if (!update_fits_lds(a.N, a.m)) return launch_update_t<1024, 32, false>(s, a);  // m > 32 and N > 256
 #define LMCMA_UPD(TB)                                          \
     do {                                                       \
-        if (emax <= 8) return launch_update_t<TB, 8, true>(s, a);   \
-        if (emax <= 16) return launch_update_t<TB, 16, true>(s, a); \
+        if (emax == 8) return launch_update_t<TB, 8, true>(s, a);   \
+        if (emax == 12) return launch_update_t<TB, 12, true>(s, a); \
+        if (emax == 16) return launch_update_t<TB, 16, true>(s, a); \
+        if (emax == 20) return launch_update_t<TB, 20, true>(s, a); \
+        if (emax == 24) return launch_update_t<TB, 24, true>(s, a); \
         return launch_update_t<TB, 32, true>(s, a);            \
     } while (0)
     if (threads == 256) LMCMA_UPD(256);

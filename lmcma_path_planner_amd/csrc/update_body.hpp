@@ -199,10 +199,17 @@ static __device__ unsigned long long g_update_stamps[16];
 #define LMCMA_STAMP(i)
 #endif
 
+// Coordinates per lane a 16-lane group keeps in registers for a vector of N parameters
+// (N <= 512): the register tile of the update kernels, and 1/16 of their LDS row stride
+__host__ __device__ constexpr int update_emax(int N)
+{
+    return N <= 128 ? 8 : N <= 192 ? 12 : N <= 256 ? 16 : N <= 320 ? 20 : N <= 384 ? 24 : 32;
+}
+
 // LDS doubles the update needs for (N, m) when TR threads read the partial rows
 __host__ __device__ inline size_t update_lds_doubles(int N, int m, int TR, bool v_lds)
 {
-    const size_t np = N <= 128 ? 128 : N <= 256 ? 256 : 512;  // 16 lanes x 8, 16 or 32 coordinates
+    const size_t np = v_lds ? 16 * (size_t)update_emax(N) : 512;  // without LDS vectors: the widest tile only
     return (v_lds ? (size_t)m * np : 0) + np + row_sum_lds_doubles(N, TR) + 2 * LMCMA_HIP_MAX_VECTORS;
 }
 
@@ -619,7 +626,7 @@ __device__ __forceinline__ SlotPlan slot_plan(int t_reg, int vec_reg, int itr, i
 // LDS doubles of the two parts (vectors by position, padded rows; norms and lj by position)
 __host__ __device__ inline size_t update_pre_lds_doubles(int N, int m)
 {
-    const size_t np = N <= 128 ? 128 : N <= 256 ? 256 : 512;
+    const size_t np = 16 * (size_t)update_emax(N);
     return (size_t)m * np + 2 * LMCMA_HIP_MAX_VECTORS;
 }
 
@@ -738,7 +745,7 @@ __device__ __forceinline__ void update_pre_body(const UpdateArgs &a, double *s_d
 // LDS doubles of the second part when TR threads read the partial rows
 __host__ __device__ inline size_t update_post_lds_doubles(int N, int m, int TR)
 {
-    const size_t np = N <= 128 ? 128 : N <= 256 ? 256 : 512;
+    const size_t np = 16 * (size_t)update_emax(N);
     return (size_t)m * np + np + row_sum_lds_doubles(N, TR) + LMCMA_HIP_MAX_VECTORS;
 }
 
