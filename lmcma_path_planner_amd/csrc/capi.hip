@@ -106,7 +106,7 @@ struct lmcma_hip_ctx {
     uint64_t *keys = nullptr;
     float *xmean_f = nullptr, *V_f = nullptr, *B_f = nullptr, *lo_f = nullptr, *hi_f = nullptr;
     SampleScalars *sc = nullptr;
-    double *weights = nullptr, *block_partials = nullptr, *partial_local = nullptr,
+    double *weights = nullptr, *block_partials = nullptr, *reduced_rows = nullptr, *partial_local = nullptr,
            *partial_all = nullptr, *xmean = nullptr, *pc = nullptr, *pc_arr = nullptr,
            *v_arr = nullptr, *nj = nullptr, *lj = nullptr;
     int32_t *t = nullptr, *vec = nullptr, *iterator = nullptr;
@@ -359,11 +359,27 @@ int do_recombine(lmcma_hip_ctx *c)
     return LMCMA_HIP_OK;
 }
 
+// Many rows of block_partials are first summed to a few by many workgroups; *src / *rows are
+// what the single workgroup after that reads.
+int reduce_if_many(lmcma_hip_ctx *c, int *rows, const double **src)
+{
+    *src = c->block_partials;
+    if (*rows < kReduceRowsFrom) return LMCMA_HIP_OK;
+    Timed tm(c, LMCMA_K_RECOMBINE);
+    HIP_TRY(launch_reduce_rows(c->stream, c->block_partials, *rows, c->N, c->reduced_rows));
+    *src = c->reduced_rows;
+    *rows = reduce_rows_out(*rows);
+    return LMCMA_HIP_OK;
+}
+
 // block_partials -> partial_local (needed when the partial sum leaves the context; the
 // update can add the block partials itself).  with_scalars: also the context's success-rule
 // count and the lowest cost, entries N and N + 1 of the row.
 int do_recombine_final(lmcma_hip_ctx *c, int rows, bool with_scalars)
 {
+    const double *src = nullptr;
+    int rc = reduce_if_many(c, &rows, &src);
+    if (rc != LMCMA_HIP_OK) return rc;
     Timed tm(c, LMCMA_K_RECOMBINE);
     FinalExtras x{};
     x.psr_parts = reinterpret_cast<const uint32_t *>(c->keys);
@@ -376,7 +392,7 @@ int do_recombine_final(lmcma_hip_ctx *c, int rows, bool with_scalars)
     // one that feeds its own update must use the update's, so that reducing first and updating
     // from the one row gives the same bits as updating from the block rows.
     const int threads = c->merge_protocol ? 1024 : update_threads(c->N, std::min(c->m, LMCMA_HIP_MAX_VECTORS));
-    HIP_TRY(launch_recombine_final(c->stream, c->block_partials, rows, c->N, c->partial_local, threads,
+    HIP_TRY(launch_recombine_final(c->stream, src, rows, c->N, c->partial_local, threads,
                                    with_scalars ? &x : nullptr));
     return LMCMA_HIP_OK;
 }
@@ -407,9 +423,13 @@ int one_generation(lmcma_hip_ctx *c)
     }
     int rows = 0;
     if ((rc = do_select(c, true, &rows, true)) != LMCMA_HIP_OK) return rc;
-    if (rows > 0) return do_update(c, c->block_partials, rows, false);
-    if ((rc = do_recombine(c)) != LMCMA_HIP_OK) return rc;
-    return do_update(c, c->block_partials, recombine_num_blocks(c->mu), false);
+    if (rows == 0) {
+        if ((rc = do_recombine(c)) != LMCMA_HIP_OK) return rc;
+        rows = recombine_num_blocks(c->mu);
+    }
+    const double *src = nullptr;
+    if ((rc = reduce_if_many(c, &rows, &src)) != LMCMA_HIP_OK) return rc;
+    return do_update(c, src, rows, false);
 }
 
 int check_ctx(const lmcma_hip_ctx *c)
@@ -537,6 +557,7 @@ int lmcma_hip_create(const lmcma_hip_config *cfg, lmcma_hip_ctx **out)
     }
     ar.add(&c->block_partials,
            (size_t)std::max(recombine_num_blocks(c->mu), select_max_partial_rows(c->first, c->nloc)) * N);
+    ar.add(&c->reduced_rows, (size_t)kReducedRowsMax * N);
     ar.add(&c->terms, nloc * 3);
     ar.add(&c->rows, nloc * ld);
     hipError_t e = ar.commit(&c->arena);

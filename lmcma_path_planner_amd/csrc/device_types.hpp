@@ -178,6 +178,13 @@ struct FinalExtras {
 };
 hipError_t launch_recombine_final(hipStream_t s, const double *block_partials, int rows, int N,
                                   double *partial_local, int threads, const FinalExtras *extras);
+// First level of the sum over many partial rows (k_reduce_rows): rows -> reduce_rows_out(rows) <=
+// kReducedRowsMax rows of dst; used above kReduceRowsFrom rows.
+constexpr int kReducedRowsMax = 32;
+constexpr int kReduceRowsFrom = 192;
+int reduce_rows_out(int rows);
+hipError_t launch_reduce_rows(hipStream_t s, const double *src, int rows, int N, double *dst);
+
 // workgroup size the update uses for m direction vectors of N parameters
 int update_threads(int N, int m);
 

@@ -78,6 +78,22 @@ __global__ __launch_bounds__(1024) void k_recombine_final(const double *__restri
     }
 }
 
+// A first level for many partial rows: rows [b chunk, (b + 1) chunk) of src -> row b of dst.
+// One workgroup reads freshly written rows at some tens of GB/s, so beyond a hundred rows or so
+// the single workgroup that consumes them is better off with a few dozen rows summed by
+// many workgroups first.
+__global__ __launch_bounds__(256) void k_reduce_rows(const double *__restrict__ src, int rows, int chunk, int N,
+                                                     double *__restrict__ dst)
+{
+    __shared__ double s_red[1024];  // row_sum_lds_doubles(N <= 512, 256)
+    const int first = blockIdx.x * chunk;
+    const int count = rows - first < chunk ? rows - first : chunk;
+    row_sums_to_lds(src + (size_t)first * N, count, N, N, 256, s_red);
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += 256)
+        dst[(size_t)blockIdx.x * N + n] = row_sums_total(s_red, N, n, row_sum_groups(N, 256));
+}
+
 // ---- update, stand-alone ------------------------------------------------------------
 // TB threads do the vector work.  The workgroup is larger when there is room: 512 threads
 // for TB = 256 (two waves per SIMD keep the whole register file per lane), all of which
@@ -163,6 +179,20 @@ hipError_t launch_recombine(hipStream_t s, const float *rows, int ld, int N, int
     const size_t lds = (size_t)nslots * ld * sizeof(double);
     hipLaunchKernelGGL(k_recombine_partial, dim3(nb), dim3(256), lds, s, rows, ld, N, first_candidate,
                        n_local, perm, weights, mu, block_partials);
+    return hipGetLastError();
+}
+
+int reduce_rows_out(int rows)
+{
+    const int chunk = (rows + kReducedRowsMax - 1) / kReducedRowsMax;
+    return (rows + chunk - 1) / chunk;
+}
+
+hipError_t launch_reduce_rows(hipStream_t s, const double *src, int rows, int N, double *dst)
+{
+    if (rows < 1 || N < 1 || N > 512) return hipErrorInvalidValue;
+    const int chunk = (rows + kReducedRowsMax - 1) / kReducedRowsMax;
+    hipLaunchKernelGGL(k_reduce_rows, dim3(reduce_rows_out(rows)), dim3(256), 0, s, src, rows, chunk, N, dst);
     return hipGetLastError();
 }
 

@@ -383,7 +383,8 @@ def test_recombine_matches_fp64_sum(hip, oracle):
                                                  (144, 512, 32, 40, 3, 48),    # 3-D, 48 waypoints, m = 32
                                                  (256, 64, 48, 56, 2, 128),    # 128 waypoints, m = 48
                                                  (33, 32, 5, 12, 3, 11),       # odd parameter count
-                                                 (288, 128, 16, 20, 3, 96)])   # 96 waypoints in 3-D
+                                                 (288, 128, 16, 20, 3, 96),    # 96 waypoints in 3-D
+                                                 (64, 8192, 8, 12, 2, 32)])    # 256 partial rows: two-level sum
 def test_device_update_follows_oracle_generation_by_generation(hip, oracle, N, lam, m, gens, dims, W):
     """Each generation the oracle is handed the device's rows and costs; its fp64
     update (the reference's order of operations) must then agree with the device's."""
@@ -426,12 +427,15 @@ def test_device_update_follows_oracle_generation_by_generation(hip, oracle, N, l
     ctx.close()
 
 
-def test_graph_run_equals_phase_by_phase_run(hip):
+@pytest.mark.parametrize("lam,m", [(512, 16), (8192, 16), (8192, 32), (20480, 8)])
+def test_graph_run_equals_phase_by_phase_run(hip, lam, m):
+    """lambda = 8192 leaves 256 partial rows (summed in two levels), 20480 goes through the
+    sorting path; m = 32 uses the one-kernel update, m <= 16 the two-part one."""
     from lmcma_path_planner_amd import grids
     prob = grids.benchmark_problem(2)
     results = []
     for mode in ("run", "phases"):
-        ctx = hip.HipContext(prob.N, 512, prob.m, dims=2, waypoints=prob.W, start=prob.start, goal=prob.goal, seed=7)
+        ctx = hip.HipContext(prob.N, lam, m, dims=2, waypoints=prob.W, start=prob.start, goal=prob.goal, seed=7)
         ctx.set_grid(prob.occ)
         ctx.set_bounds(prob.lo, prob.hi)
         ctx.opt_init(prob.x0, prob.sigma0)
@@ -446,7 +450,7 @@ def test_graph_run_equals_phase_by_phase_run(hip):
         results.append(st)
         ctx.close()
     a, b = results
-    assert a["itr"] == b["itr"] == 27 and a["counteval"] == 27 * 512
+    assert a["itr"] == b["itr"] == 27 and a["counteval"] == 27 * lam
     np.testing.assert_array_equal(a["xmean"], b["xmean"])     # deterministic kernels: bit-identical
     assert a["sigma"] == b["sigma"] and a["best_f"] == b["best_f"]
 
