@@ -6,9 +6,10 @@
 // nearest occupied cell; squared, they are integers, so any exact algorithm gives the same
 // bits.  Here: three separable passes over squared distances held as uint32,
 //     g(a) = min over a' of f(a') + (a - a')^2      along x, then y, then z.
-// Along x the input is binary and a line needs two scans; along y and z a lane walks a
-// column with an integer lower-envelope scan.  The y and z passes stage tiles of 16 to 64
-// neighbouring columns in LDS, so that every global access is a contiguous run along x.
+// Along x the input is binary and a line needs two scans; along y and z every output searches
+// outwards from its own position until k^2 can no longer beat the best value found.  The y
+// and z passes stage tiles of 16 to 64 neighbouring columns in LDS, so that every global
+// access is a contiguous run along x.
 #include <utility>
 
 #include "device_types.hpp"
@@ -75,29 +76,46 @@ __global__ __launch_bounds__(256) void k_edt_x(const uint8_t *__restrict__ occ, 
     }
 }
 
-// along an axis with a stride: element (o, a, x) lives at o * outer_stride + a * axis_stride + x.
-// One wave stages TX neighbouring columns of one o (all n positions of the axis) in LDS and
-// one lane walks one column with the integer lower-envelope scan of Meijster, Roerdink and
-// Hesselink: a forward sweep keeps the stack of parabolas (s = their apex, t = the position
-// from which each is the lowest), a backward sweep reads the minimum off it.  Every step is
-// exact integer arithmetic: with kEdtFar < 2^30 and n <= 1024 nothing leaves 31 bits.
-// O(n) per column whatever the map looks like.
-template <int TX>
-__global__ __launch_bounds__(64) void k_edt_axis(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int nx,
-                                                 int n, long axis_stride, long outer_stride, int n_outer)
+// squared distance -> distance (float) and the state cost 1 / max(distance, d_min); a grid
+// without any occupied cell reads 1e6 cells everywhere
+struct EdtOut {
+    float *dist, *cost;  // either may be null
+    double d_min;
+};
+
+__device__ __forceinline__ void edt_store(const EdtOut &f, long i, uint32_t v)
 {
-    extern __shared__ uint32_t s_mem[];
-    int *g = reinterpret_cast<int *>(s_mem);        // [n][TX] the column values
-    uint32_t *stack = s_mem + (size_t)n * TX;       // [n][TX] s | t << 16
-    constexpr int AY = 64 / TX;
-    const int lane = threadIdx.x, tx = lane % TX, ta = lane / TX;
+    const float d = v >= kEdtFar ? 1.0e6f : (float)sqrt((double)v);
+    if (f.dist) f.dist[i] = d;
+    if (f.cost) f.cost[i] = (float)(1.0 / fmax((double)d, f.d_min));
+}
+
+// along an axis with a stride: element (o, a, x) lives at o * outer_stride + a * axis_stride + x.
+// A workgroup stages TX neighbouring columns of one o (all n positions of the axis) in LDS and
+// computes one of `segs` interleaved shares of the positions (a small grid has too few column
+// tiles to fill the chip otherwise; inputs and outputs are different arrays for that reason).
+// Every output searches outwards from its own position, eight steps (sixteen LDS reads in
+// flight) at a time, and stops once k^2 can no longer beat the best value found: on a map
+// with obstacles every few cells that is one or two rounds, on an empty one n / 8.
+// LAST: the pass writes distances / costs (fin) instead of squared distances.
+template <int TX, bool LAST>
+__global__ __launch_bounds__(256) void k_edt_axis(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int nx,
+                                                  int n, long axis_stride, long outer_stride, int n_outer, int segs,
+                                                  const EdtOut fin)
+{
+    extern __shared__ uint32_t s_tile[];  // [n][TX]
+    constexpr int AY = 256 / TX;          // positions of the axis handled at once
+    constexpr int KB = 8;                 // steps per round
+    const int tx = threadIdx.x % TX, ta = threadIdx.x / TX;
     const int xtiles = (nx + TX - 1) / TX;
-    const long tiles = (long)xtiles * n_outer;
-    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const long work_items = (long)xtiles * n_outer * segs;
+    for (long work = blockIdx.x; work < work_items; work += gridDim.x) {
+        const int seg = (int)(work % segs);
+        const long tile = work / segs;
         const int o = (int)(tile / xtiles), x = (int)(tile % xtiles) * TX + tx;
         const bool live = x < nx;
         const long base = (long)o * outer_stride + x;
-        __syncthreads();  // the previous tile's columns are finished
+        __syncthreads();  // the previous tile has been searched
         for (int a0 = ta; a0 < n; a0 += 8 * AY) {
             uint32_t v[8];
 #pragma unroll
@@ -108,94 +126,76 @@ __global__ __launch_bounds__(64) void k_edt_axis(const uint32_t *__restrict__ in
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int a = a0 + u * AY;
-                if (a < n) g[a * TX + tx] = (int)v[u];
+                if (a < n) s_tile[a * TX + tx] = v[u];
             }
         }
         __syncthreads();
-        if (lane < TX && live) {
-            // F(p, i) = (p - i)^2 + g(i): the parabola with apex i, at position p
-            int q = 0;
-            stack[tx] = 0u;  // s = 0, t = 0
-            int sq = 0, tq = 0, gq = g[tx];  // top of the stack, and g at its apex
-            for (int u = 1; u < n; ++u) {
-                const int gu = g[u * TX + tx];
-                // parabolas that u beats already where they start are never the lowest
-                while (q >= 0 && (tq - sq) * (tq - sq) + gq > (tq - u) * (tq - u) + gu) {
-                    --q;
-                    if (q >= 0) {
-                        const uint32_t e = stack[q * TX + tx];
-                        sq = (int)(e & 0xffffu);
-                        tq = (int)(e >> 16);
-                        gq = g[sq * TX + tx];
-                    }
+        if (!live) continue;
+        for (int a = ta + seg * AY; a < n; a += AY * segs) {
+            uint32_t best = s_tile[a * TX + tx];
+            for (int k0 = 1; k0 < n && (uint32_t)(k0 * k0) < best; k0 += KB) {
+                uint32_t lo[KB], hi[KB];
+#pragma unroll
+                for (int u = 0; u < KB; ++u) {
+                    const int d = a - (k0 + u), e = a + (k0 + u);
+                    lo[u] = s_tile[(d < 0 ? 0 : d) * TX + tx];
+                    hi[u] = s_tile[(e >= n ? n - 1 : e) * TX + tx];
                 }
-                if (q < 0) {
-                    q = 0;
-                    sq = u; tq = 0; gq = gu;
-                    stack[tx] = (uint32_t)u;
-                } else {
-                    // first position where u is lower than the top: 1 + floor of the crossing
-                    const int w = 1 + (u * u - sq * sq + gu - gq) / (2 * (u - sq));
-                    if (w < n) {
-                        ++q;
-                        sq = u; tq = w; gq = gu;
-                        stack[q * TX + tx] = (uint32_t)u | ((uint32_t)w << 16);
-                    }
+#pragma unroll
+                for (int u = 0; u < KB; ++u) {
+                    const int k = k0 + u;
+                    const uint32_t kk = (uint32_t)(k * k);
+                    // positions past the ends were read at a clamped index: dropped here
+                    if (a - k >= 0) best = min(best, lo[u] + kk);
+                    if (a + k < n) best = min(best, hi[u] + kk);
                 }
             }
-            for (int u = n - 1; u >= 0; --u) {
-                const int d = (u - sq) * (u - sq) + gq;
-                out[base + (long)u * axis_stride] = d >= (int)kEdtFar ? kEdtFar : (uint32_t)d;
-                if (u == tq && q > 0) {
-                    --q;
-                    const uint32_t e = stack[q * TX + tx];
-                    sq = (int)(e & 0xffffu);
-                    tq = (int)(e >> 16);
-                    gq = g[sq * TX + tx];
-                }
-            }
+            if (LAST) edt_store(fin, base + (long)a * axis_stride, best);
+            else out[base + (long)a * axis_stride] = best;
         }
     }
 }
 
-// squared distance -> distance (float) and the state cost 1 / max(distance, d_min); a grid
-// without any occupied cell reads 1e6 cells everywhere
-__global__ __launch_bounds__(256) void k_edt_finish(const uint32_t *__restrict__ d2, long cells, double d_min,
-                                                    float *__restrict__ dist, float *__restrict__ cost)
+// the same conversion as a pass of its own (a 1-D grid has no y or z pass to carry it)
+__global__ __launch_bounds__(256) void k_edt_finish(const uint32_t *__restrict__ d2, long cells, const EdtOut fin)
 {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < cells; i += (long)gridDim.x * 256) {
-        const uint32_t v = d2[i];
-        const float d = v >= kEdtFar ? 1.0e6f : (float)sqrt((double)v);
-        if (dist) dist[i] = d;
-        if (cost) cost[i] = (float)(1.0 / fmax((double)d, d_min));
-    }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < cells; i += (long)gridDim.x * 256) edt_store(fin, i, d2[i]);
 }
 
-template <int TX>
+template <int TX, bool LAST>
 hipError_t launch_axis(hipStream_t s, const uint32_t *in, uint32_t *out, int nx, int n, long axis_stride,
-                       long outer_stride, int n_outer)
+                       long outer_stride, int n_outer, const EdtOut &fin)
 {
-    const size_t lds = 2 * (size_t)n * TX * sizeof(uint32_t);
+    const size_t lds = (size_t)n * TX * sizeof(uint32_t);
     static size_t configured = 48 * 1024;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edt_axis<TX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edt_axis<TX, LAST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
     const long tiles = (long)((nx + TX - 1) / TX) * n_outer;
-    const int blocks = (int)(tiles < 16384 ? tiles : 16384);
-    hipLaunchKernelGGL(k_edt_axis<TX>, dim3(blocks), dim3(64), lds, s, in, out, nx, n, axis_stride, outer_stride, n_outer);
+    // about four workgroups per CU, each with at least one round of positions
+    int segs = (int)((1024 + tiles - 1) / tiles);
+    const int max_segs = (n + (256 / TX) - 1) / (256 / TX);
+    if (segs > max_segs) segs = max_segs;
+    if (segs < 1) segs = 1;
+    const long work = tiles * segs;
+    const int blocks = (int)(work < 16384 ? work : 16384);
+    hipLaunchKernelGGL((k_edt_axis<TX, LAST>), dim3(blocks), dim3(256), lds, s, in, out, nx, n, axis_stride, outer_stride,
+                       n_outer, segs, fin);
     return hipGetLastError();
 }
 
-// columns per wave: as many as leave the tile and the stacks (8 n bytes per column) within 128 KiB
+// columns per workgroup: as many as keep the tile within 32 KiB (four workgroups per CU hide the
+// LDS latency of a round better than two with twice the columns), at least 16 (64-byte runs)
+template <bool LAST>
 hipError_t edt_axis(hipStream_t s, const uint32_t *in, uint32_t *out, int nx, int n, long axis_stride,
-                    long outer_stride, int n_outer)
+                    long outer_stride, int n_outer, const EdtOut &fin)
 {
-    if (n <= 256) return launch_axis<64>(s, in, out, nx, n, axis_stride, outer_stride, n_outer);
-    if (n <= 512) return launch_axis<32>(s, in, out, nx, n, axis_stride, outer_stride, n_outer);
-    return launch_axis<16>(s, in, out, nx, n, axis_stride, outer_stride, n_outer);
+    if (n <= 128) return launch_axis<64, LAST>(s, in, out, nx, n, axis_stride, outer_stride, n_outer, fin);
+    if (n <= 256) return launch_axis<32, LAST>(s, in, out, nx, n, axis_stride, outer_stride, n_outer, fin);
+    return launch_axis<16, LAST>(s, in, out, nx, n, axis_stride, outer_stride, n_outer, fin);
 }
 
 }  // namespace
@@ -217,19 +217,17 @@ hipError_t launch_edt(hipStream_t s, const uint8_t *occ, int nx, int ny, int nz,
         if (e != hipSuccess) return e;
     }
     uint32_t *cur = d2, *other = d2 + cells;
+    const EdtOut fin{dist, cost, d_min};
+    // the last pass along an axis writes the distances and costs itself
     if (ny > 1) {
-        hipError_t e = edt_axis(s, cur, other, nx, ny, nx, (long)nx * ny, nz);
-        if (e != hipSuccess) return e;
+        hipError_t e = nz > 1 ? edt_axis<false>(s, cur, other, nx, ny, nx, (long)nx * ny, nz, fin)
+                              : edt_axis<true>(s, cur, other, nx, ny, nx, (long)nx * ny, nz, fin);
+        if (e != hipSuccess || nz == 1) return e;
         std::swap(cur, other);
     }
-    if (nz > 1) {
-        hipError_t e = edt_axis(s, cur, other, nx, nz, (long)nx * ny, nx, ny);
-        if (e != hipSuccess) return e;
-        std::swap(cur, other);
-    }
+    if (nz > 1) return edt_axis<true>(s, cur, other, nx, nz, (long)nx * ny, nx, ny, fin);
     const long groups = (cells + 255) / 256;
-    hipLaunchKernelGGL(k_edt_finish, dim3((int)(groups < 16384 ? groups : 16384)), dim3(256), 0, s, cur, cells, d_min,
-                       dist, cost);
+    hipLaunchKernelGGL(k_edt_finish, dim3((int)(groups < 16384 ? groups : 16384)), dim3(256), 0, s, cur, cells, fin);
     return hipGetLastError();
 }
 
