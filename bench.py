@@ -226,6 +226,12 @@ def main():
                          "bytes_per_launch": per_kernel[dominant]["bytes"],
                          "avg_launch_us": per_kernel[dominant]["avg_us"],
                          "event_bracket_us": per_kernel[dominant]["bracket_us"],
+                         # the whole generation against the same peak: algorithmic bytes per
+                         # candidate-trajectory x candidates per second (all ranks)
+                         "generation_achieved": lam_total * args.steps / elapsed *
+                         prob.algorithmic_bytes_per_candidate(lam_local) / 1e9,
+                         "generation_frac": lam_total * args.steps / elapsed *
+                         prob.algorithmic_bytes_per_candidate(lam_local) / 1e9 / (HBM_PEAK_GBS * world),
                          "bracket_overhead_us": event_overhead_us,
                          "empty_bracket_us": empty_bracket_us},
             "kernels": per_kernel,
