@@ -384,7 +384,11 @@ def test_recombine_matches_fp64_sum(hip, oracle):
                                                  (256, 64, 48, 56, 2, 128),    # 128 waypoints, m = 48
                                                  (33, 32, 5, 12, 3, 11),       # odd parameter count
                                                  (288, 128, 16, 20, 3, 96),    # 96 waypoints in 3-D
-                                                 (64, 8192, 8, 12, 2, 32)])    # 256 partial rows: two-level sum
+                                                 (64, 8192, 8, 12, 2, 32),     # 256 partial rows: two-level sum
+                                                 (512, 64, 16, 20, 2, 256),    # longest vectors, two-part update
+                                                 (512, 96, 64, 70, 2, 256),    # largest store: vectors stay in global memory
+                                                 (320, 32, 24, 30, 2, 160),    # 20 coordinates per lane, m = 24
+                                                 (4, 2, 2, 6, 2, 2)])          # smallest population
 def test_device_update_follows_oracle_generation_by_generation(hip, oracle, N, lam, m, gens, dims, W):
     """Each generation the oracle is handed the device's rows and costs; its fp64
     update (the reference's order of operations) must then agree with the device's."""
