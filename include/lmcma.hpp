@@ -15,7 +15,9 @@
 // in fp64 in the reference's order of operations, or on the device when
 // useDeviceUpdate(true) is set.
 //
-// SepCMA and CMAChol (reference lmcma.hpp:152-239) are not provided.
+// SepCMA (reference lmcma.hpp:152-190) is provided with the same division of work:
+// sampling (and, with a trajectory problem, scoring) on the GPU, its O(mu N) update on the
+// host.  CMAChol (reference lmcma.hpp:199-239) is not provided.
 #ifndef LMCMA_AMD_LMCMA_HPP
 #define LMCMA_AMD_LMCMA_HPP
 
@@ -119,6 +121,42 @@ public:
 private:
     LMCMA(const LMCMA &);
     LMCMA &operator=(const LMCMA &);
+    Impl *impl;
+};
+
+// Separable CMA-ES (reference lmcma.hpp:152-190, lmcma.cpp:466-577): a diagonal covariance.
+// Candidates x = xmean + sigma D z are drawn on the device from normals of the reference's
+// sequential generator (z <- L z first when a covariance is given, lmcma.cpp:212-218); the
+// update (lmcma.cpp:530-577) runs on the host in fp64 in the reference's order of operations.
+class SepCMA : public CMABase {
+public:
+    SepCMA(double *initialParams, int lambda = 0, double *loBounds = 0, double *hiBounds = 0,
+           double sigma = 1.0, double *covariance = 0, int inseed = 0, bool verbose = false);
+    ~SepCMA();
+    void init(int N);
+    void getNextParameterVector(double *params, int N);
+    void setEvaluationFeedback(double *feedbacks, int numFeedbacks);
+    void sample();
+    void update();
+
+    // ---- extensions, as for LMCMA ---------------------------------------------------
+    void setDevice(int ordinal);
+    void setTrajectoryProblem(const LMCMATrajectoryProblem &problem);
+    void evaluatePopulation();
+    void step(int generations = 1) { for (int g = 0; g < generations; ++g) evaluatePopulation(); }
+    int dimension() const;
+    int populationSize() const;
+    int generation() const;
+    double stepSize() const;
+    void mean(double *xmean_out) const;       // [N]
+    void diagonal(double *diagD_out) const;   // [N] square roots of the diagonal covariance
+    void population(double *rows_out) const;  // [lambda][N]
+
+    struct Impl;
+
+private:
+    SepCMA(const SepCMA &);
+    SepCMA &operator=(const SepCMA &);
     Impl *impl;
 };
 

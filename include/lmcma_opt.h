@@ -26,6 +26,10 @@ const char *lmcma_opt_last_error(void);
  * by the handle.  lambda < 1: 4 + int(3 ln N); seed < 1: clock-derived.        */
 int lmcma_opt_create(const double *initial, const double *lo, const double *hi, const double *cov,
                      int n, int lambda, double sigma, int seed, int verbose, lmcma_opt **out);
+/* SepCMA::SepCMA (L/lmcma.hpp:182-184): the same arguments; the handle then drives the
+ * separable CMA-ES through the functions below (set_options: only `device` applies).  */
+int lmcma_opt_create_sep(const double *initial, const double *lo, const double *hi, const double *cov,
+                         int n, int lambda, double sigma, int seed, int verbose, lmcma_opt **out);
 int lmcma_opt_destroy(lmcma_opt *o);
 
 /* extensions of include/lmcma.hpp; call before lmcma_opt_init.  m < 1: lambda */
@@ -55,6 +59,8 @@ int lmcma_opt_get_info(lmcma_opt *o, lmcma_opt_info *info);
 int lmcma_opt_get_mean(lmcma_opt *o, double *xmean);
 int lmcma_opt_get_population(lmcma_opt *o, double *rows);
 int lmcma_opt_get_last_costs(lmcma_opt *o, double *costs);
+/* SepCMA handles: diagD (L/lmcma.hpp:158), the square roots of the diagonal covariance */
+int lmcma_opt_get_diagonal(lmcma_opt *o, double *diag_d);
 
 /* ---- host helpers ---------------------------------------------------------------- */
 

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <exception>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -35,7 +36,9 @@ int guarded(F &&f)
 struct lmcma_opt {
     std::vector<double> initial, lo, hi, cov;
     LMCMA *opt = nullptr;
-    ~lmcma_opt() { delete opt; }
+    SepCMA *sep = nullptr;   // a handle holds one of the two optimisers
+    ~lmcma_opt() { delete opt; delete sep; }
+    CMABase *base() { return opt ? static_cast<CMABase *>(opt) : static_cast<CMABase *>(sep); }
 };
 
 extern "C" {
@@ -58,6 +61,22 @@ int lmcma_opt_create(const double *initial, const double *lo, const double *hi, 
     });
 }
 
+int lmcma_opt_create_sep(const double *initial, const double *lo, const double *hi, const double *cov,
+                         int n, int lambda, double sigma, int seed, int verbose, lmcma_opt **out)
+{
+    if (!out || n < 1) { g_err = "lmcma_opt_create_sep: bad arguments"; return -1; }
+    return guarded([&] {
+        lmcma_opt *h = new lmcma_opt();
+        if (initial) h->initial.assign(initial, initial + n);
+        if (lo) h->lo.assign(lo, lo + n);
+        if (hi) h->hi.assign(hi, hi + n);
+        if (cov) h->cov.assign(cov, cov + (size_t)n * n);
+        h->sep = new SepCMA(initial ? h->initial.data() : 0, lambda, lo ? h->lo.data() : 0,
+                            hi ? h->hi.data() : 0, sigma, cov ? h->cov.data() : 0, seed, verbose != 0);
+        *out = h;
+    });
+}
+
 int lmcma_opt_destroy(lmcma_opt *o)
 {
     return guarded([&] { delete o; });
@@ -67,6 +86,11 @@ int lmcma_opt_set_options(lmcma_opt *o, int m, int device, int philox, int devic
 {
     if (!o) { g_err = "null handle"; return -1; }
     return guarded([&] {
+        if (o->sep) {
+            if (philox || device_update) throw std::invalid_argument("SepCMA: host normals and host update only");
+            o->sep->setDevice(device);
+            return;
+        }
         o->opt->setDirectionVectors(m);
         o->opt->setDevice(device);
         o->opt->usePhiloxSampling(philox != 0);
@@ -93,46 +117,60 @@ int lmcma_opt_set_problem(lmcma_opt *o, int dims, int waypoints, int nx, int ny,
         }
         p.w_len = w_len; p.w_grid = w_grid; p.w_smooth = w_smooth;
         p.pad_mode = pad_mode;
-        o->opt->setTrajectoryProblem(p);
+        if (o->sep) o->sep->setTrajectoryProblem(p);
+        else o->opt->setTrajectoryProblem(p);
     });
 }
 
 int lmcma_opt_init(lmcma_opt *o, int N)
 {
     if (!o) { g_err = "null handle"; return -1; }
-    return guarded([&] { o->opt->init(N); });
+    return guarded([&] { o->base()->init(N); });
 }
 
 int lmcma_opt_ask(lmcma_opt *o, double *params, int N)
 {
     if (!o || !params) { g_err = "null argument"; return -1; }
-    return guarded([&] { o->opt->getNextParameterVector(params, N); });
+    return guarded([&] { o->base()->getNextParameterVector(params, N); });
 }
 
 int lmcma_opt_tell(lmcma_opt *o, const double *feedbacks, int num_feedbacks)
 {
     if (!o || !feedbacks) { g_err = "null argument"; return -1; }
-    return guarded([&] { o->opt->setEvaluationFeedback(const_cast<double *>(feedbacks), num_feedbacks); });
+    return guarded([&] { o->base()->setEvaluationFeedback(const_cast<double *>(feedbacks), num_feedbacks); });
 }
 
 int lmcma_opt_done(lmcma_opt *o)
 {
     if (!o) { g_err = "null handle"; return -1; }
     int done = 0;
-    int rc = guarded([&] { done = o->opt->isBehaviorLearningDone() ? 1 : 0; });
+    int rc = guarded([&] { done = o->base()->isBehaviorLearningDone() ? 1 : 0; });
     return rc < 0 ? rc : done;
 }
 
 int lmcma_opt_step(lmcma_opt *o, int generations)
 {
     if (!o) { g_err = "null handle"; return -1; }
-    return guarded([&] { o->opt->step(generations); });
+    return guarded([&] {
+        if (o->sep) o->sep->step(generations);
+        else o->opt->step(generations);
+    });
 }
 
 int lmcma_opt_get_info(lmcma_opt *o, lmcma_opt_info *info)
 {
     if (!o || !info) { g_err = "null argument"; return -1; }
     return guarded([&] {
+        if (o->sep) {
+            info->n = o->sep->dimension();
+            info->lambda = o->sep->populationSize();
+            info->m = 0;
+            info->generation = o->sep->generation();
+            info->counteval = o->sep->counteval;
+            info->best_f = o->sep->BestF;
+            info->sigma = o->sep->stepSize();
+            return;
+        }
         info->n = o->opt->dimension();
         info->lambda = o->opt->populationSize();
         info->m = o->opt->directionVectors();
@@ -146,19 +184,37 @@ int lmcma_opt_get_info(lmcma_opt *o, lmcma_opt_info *info)
 int lmcma_opt_get_mean(lmcma_opt *o, double *xmean)
 {
     if (!o || !xmean) { g_err = "null argument"; return -1; }
-    return guarded([&] { o->opt->mean(xmean); });
+    return guarded([&] {
+        if (o->sep) o->sep->mean(xmean);
+        else o->opt->mean(xmean);
+    });
 }
 
 int lmcma_opt_get_population(lmcma_opt *o, double *rows)
 {
     if (!o || !rows) { g_err = "null argument"; return -1; }
-    return guarded([&] { o->opt->population(rows); });
+    return guarded([&] {
+        if (o->sep) o->sep->population(rows);
+        else o->opt->population(rows);
+    });
 }
 
 int lmcma_opt_get_last_costs(lmcma_opt *o, double *costs)
 {
     if (!o || !costs) { g_err = "null argument"; return -1; }
-    return guarded([&] { o->opt->lastCosts(costs); });
+    return guarded([&] {
+        if (!o->opt) throw std::invalid_argument("last costs are kept by LMCMA handles only");
+        o->opt->lastCosts(costs);
+    });
+}
+
+int lmcma_opt_get_diagonal(lmcma_opt *o, double *diag_d)
+{
+    if (!o || !diag_d) { g_err = "null argument"; return -1; }
+    return guarded([&] {
+        if (!o->sep) throw std::invalid_argument("only SepCMA handles have a diagonal");
+        o->sep->diagonal(diag_d);
+    });
 }
 
 /* ---- host helpers ------------------------------------------------------------------- */

@@ -29,6 +29,8 @@ def _f64(a):
 
 
 class LMCMA:
+    _create = "lmcma_opt_create"
+
     def __init__(self, initialParams, lambda_=0, loBounds=None, hiBounds=None, sigma=1.0, covariance=None,
                  inseed=0, verbose=False):
         self.lib = _lib.load()
@@ -41,9 +43,9 @@ class LMCMA:
             raise ValueError("give initialParams or bounds so the dimension is known")
         self._n_hint = n
         self._h = ctypes.c_void_p()
-        check_opt(self.lib.lmcma_opt_create(_dp(init), _dp(lo), _dp(hi), _dp(cov), n, int(lambda_), float(sigma),
-                                            int(inseed), 1 if verbose else 0, ctypes.byref(self._h)),
-                  "lmcma_opt_create")
+        check_opt(getattr(self.lib, self._create)(_dp(init), _dp(lo), _dp(hi), _dp(cov), n, int(lambda_), float(sigma),
+                                                  int(inseed), 1 if verbose else 0, ctypes.byref(self._h)),
+                  self._create)
         self.N = None
 
     def close(self):
@@ -140,6 +142,20 @@ class LMCMA:
     def lastCosts(self):
         out = np.empty(self.populationSize, dtype=np.float64)
         check_opt(self.lib.lmcma_opt_get_last_costs(self._h, _dp(out)), "lmcma_opt_get_last_costs")
+        return out
+
+
+class SepCMA(LMCMA):
+    """Separable CMA-ES with the reference's interface (lmcma.hpp:152-190); sampling and, with a
+    trajectory problem, scoring on the device, the update on the host."""
+    _create = "lmcma_opt_create_sep"
+
+    def setOptions(self, device=0):
+        check_opt(self.lib.lmcma_opt_set_options(self._h, 0, int(device), 0, 0), "lmcma_opt_set_options")
+
+    def diagonal(self):
+        out = np.empty(self.N, dtype=np.float64)
+        check_opt(self.lib.lmcma_opt_get_diagonal(self._h, _dp(out)), "lmcma_opt_get_diagonal")
         return out
 
 

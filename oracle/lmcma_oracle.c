@@ -1050,3 +1050,135 @@ void orc_edt_exact(const uint8_t *occ, int nx, int ny, int nz, float *dist)
     for (size_t i = 0; i < cells; ++i) dist[i] = (float)sqrt(g[i]);
     free(g); free(f); free(d); free(v); free(zz);
 }
+
+/* ---- Separable CMA-ES: SepCMA of L/lmcma.hpp:152-190, L/lmcma.cpp:466-577 ------------ */
+struct orc_sep {
+    int N, lambda, mu, itr;
+    double mueff, sigma, cc, c1, cmu, ccov1, ccovmu, chiN, cs, damps;
+    double *weights, *xmean, *xold, *arx, *arz, *arfitness, *diagD, *diagC, *pc, *ps, *lo, *hi, *L;
+    int *arindex;
+    orc_rng rng;
+};
+
+static void sep_sample(orc_sep *o)
+{
+    /* L/lmcma.cpp:519-528 with sampleStandardNormal :212-218 and applyBoundaries :220-230 */
+    int N = o->N;
+    for (int i = 0; i < o->lambda; ++i) {
+        double *z = &o->arz[(size_t)i * N];
+        for (int n = 0; n < N; ++n) z[n] = orc_rng_gauss(&o->rng);
+        if (o->L) orc_apply_cov_l(o->L, z, N);
+        for (int k = 0; k < N; ++k)
+            o->arx[(size_t)i * N + k] = o->xmean[k] + o->sigma * o->diagD[k] * z[k];
+    }
+    for (int i = 0; i < o->lambda; ++i)
+        for (int k = 0; k < N; ++k) {
+            double *x = &o->arx[(size_t)i * N + k];
+            if (o->lo) *x = fmax(*x, o->lo[k]);
+            if (o->hi) *x = fmin(*x, o->hi[k]);
+        }
+}
+
+orc_sep *orc_sep_create(int N, int lambda, const double *initial, const double *lo, const double *hi,
+                        double sigma, const double *cov, long seed)
+{
+    orc_sep *o = (orc_sep *)calloc(1, sizeof(orc_sep));
+    o->N = N;
+    orc_rng_start(&o->rng, (unsigned long)seed);
+    if (lambda < 1) lambda = 4 + (int)(3 * log((double)N));
+    o->lambda = lambda;
+    o->mu = lambda / 2;
+    o->weights = (double *)calloc((size_t)(o->mu > 0 ? o->mu : 1), sizeof(double));
+    double sw = 0;
+    for (int i = 0; i < o->mu; ++i) {
+        o->weights[i] = log((double)o->mu + 0.5) - log((double)(1 + i));
+        sw += o->weights[i];
+    }
+    for (int i = 0; i < o->mu; ++i) {
+        o->weights[i] /= sw;
+        o->mueff += o->weights[i] * o->weights[i];
+    }
+    o->mueff = 1.0 / o->mueff;
+    o->xmean = (double *)calloc((size_t)N, sizeof(double));
+    o->xold = (double *)calloc((size_t)N, sizeof(double));
+    if (initial) for (int i = 0; i < N; ++i) o->xmean[i] = initial[i];
+    else for (int i = 0; i < N; ++i) o->xmean[i] = orc_rng_uniform(&o->rng);
+    o->lo = dup_d(lo, N);
+    o->hi = dup_d(hi, N);
+    if (cov) {
+        o->L = (double *)calloc((size_t)N * N, sizeof(double));
+        orc_cholesky(cov, o->L, N);
+    }
+    o->sigma = sigma;
+    o->arx = (double *)calloc((size_t)N * lambda, sizeof(double));
+    o->arz = (double *)calloc((size_t)N * lambda, sizeof(double));
+    o->arfitness = (double *)calloc((size_t)lambda, sizeof(double));
+    o->arindex = (int *)calloc((size_t)lambda, sizeof(int));
+    o->diagD = (double *)calloc((size_t)N, sizeof(double));
+    o->diagC = (double *)calloc((size_t)N, sizeof(double));
+    o->pc = (double *)calloc((size_t)N, sizeof(double));
+    o->ps = (double *)calloc((size_t)N, sizeof(double));
+    for (int i = 0; i < N; ++i) o->diagD[i] = o->diagC[i] = 1;
+    /* L/lmcma.cpp:504-514 */
+    o->cc = 1.0 / lambda;
+    o->c1 = 2.0 / (pow(N + 1.3, 2.0) + o->mueff);
+    o->cmu = fmin(1.0 - o->c1, 2.0 * (o->mueff - 2.0 + 1.0 / o->mueff) / (pow(N + 2.0, 2.0) + o->mueff));
+    o->ccov1 = fmin(1.0, o->c1 * (N + 1.5) / 3.0);
+    o->ccovmu = fmin(1.0 - o->ccov1, o->cmu * (N + 1.5) / 3);
+    o->chiN = sqrt((double)N) * (1.0 - 1.0 / (4.0 * N) + 1 / (21.0 * N * N));
+    o->cs = (o->mueff + 2.0) / (N + o->mueff + 5.0);
+    o->damps = 1.0 + 2 * fmax(0.0, sqrt((o->mueff - 1.0) / (N + 1.0)) - 1.0) + o->cs;
+    sep_sample(o);
+    return o;
+}
+
+void orc_sep_destroy(orc_sep *o)
+{
+    if (!o) return;
+    free(o->weights); free(o->xmean); free(o->xold); free(o->arx); free(o->arz); free(o->arfitness);
+    free(o->diagD); free(o->diagC); free(o->pc); free(o->ps); free(o->lo); free(o->hi); free(o->L);
+    free(o->arindex);
+    free(o);
+}
+
+/* one generation's feedback: SepCMA::update (L/lmcma.cpp:530-577), then sample */
+void orc_sep_tell_all(orc_sep *o, const double *fitness)
+{
+    int N = o->N, mu = o->mu;
+    memcpy(o->arfitness, fitness, (size_t)o->lambda * sizeof(double));
+    orc_sort(o->lambda, o->arfitness, o->arindex);
+    for (int i = 0; i < N; ++i) { o->xold[i] = o->xmean[i]; o->xmean[i] = 0; }
+    for (int i = 0; i < mu; ++i) {
+        const double *x = &o->arx[(size_t)o->arindex[i] * N];
+        for (int j = 0; j < N; ++j) o->xmean[j] += o->weights[i] * x[j];
+    }
+    double norm_ps = 0;
+    for (int i = 0; i < N; ++i) {
+        o->ps[i] = (1 - o->cs) * o->ps[i] +
+                   sqrt(o->cs * (2 - o->cs) * o->mueff) * (1. / o->diagD[i]) * (o->xmean[i] - o->xold[i]) / o->sigma;
+        norm_ps += o->ps[i] * o->ps[i];
+    }
+    norm_ps = sqrt(norm_ps);
+    for (int i = 0; i < N; ++i)
+        o->pc[i] = (1 - o->cc) * o->pc[i] + sqrt(o->cc * (2 - o->cc) * o->mueff) * (o->xmean[i] - o->xold[i]) / o->sigma;
+    for (int i = 0; i < N; ++i) {
+        double val = 0;
+        for (int j = 0; j < mu; ++j) {
+            double z = o->arz[(size_t)o->arindex[j] * N + i];
+            val += o->weights[j] * z * z;
+        }
+        o->diagC[i] = (1 - o->ccov1 - o->ccovmu) * o->diagC[i] + o->ccov1 * o->pc[i] * o->pc[i] +
+                      o->ccovmu * (o->diagC[i] * val);
+    }
+    o->sigma *= exp((o->cs / o->damps) * (norm_ps / o->chiN - 1));
+    for (int i = 0; i < N; ++i) o->diagD[i] = sqrt(o->diagC[i]);
+    o->itr++;
+    sep_sample(o);
+}
+
+void orc_sep_set_arx(orc_sep *o, const double *rows) { memcpy(o->arx, rows, (size_t)o->lambda * o->N * sizeof(double)); }
+int orc_sep_lambda(const orc_sep *o) { return o->lambda; }
+double orc_sep_sigma(const orc_sep *o) { return o->sigma; }
+const double *orc_sep_arx(const orc_sep *o) { return o->arx; }
+const double *orc_sep_xmean(const orc_sep *o) { return o->xmean; }
+const double *orc_sep_diag(const orc_sep *o) { return o->diagD; }

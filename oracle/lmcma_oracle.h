@@ -145,6 +145,19 @@ void orc_8ssedt(const uint8_t *inside, int width, int height, int *signed_dist,
 /* exact Euclidean distance (in cells) to the nearest occupied cell, 2-D or 3-D */
 void orc_edt_exact(const uint8_t *occ, int nx, int ny, int nz, float *dist);
 
+/* ---- Separable CMA-ES (SepCMA, L/lmcma.hpp:152-190, L/lmcma.cpp:466-577) ------------- */
+typedef struct orc_sep orc_sep;
+orc_sep *orc_sep_create(int N, int lambda, const double *initial, const double *lo, const double *hi,
+                        double sigma, const double *cov, long seed);
+void orc_sep_destroy(orc_sep *o);
+void orc_sep_tell_all(orc_sep *o, const double *fitness);
+void orc_sep_set_arx(orc_sep *o, const double *rows);
+int orc_sep_lambda(const orc_sep *o);
+double orc_sep_sigma(const orc_sep *o);
+const double *orc_sep_arx(const orc_sep *o);
+const double *orc_sep_xmean(const orc_sep *o);
+const double *orc_sep_diag(const orc_sep *o);
+
 #ifdef __cplusplus
 }
 #endif

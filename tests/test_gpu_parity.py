@@ -596,6 +596,48 @@ def test_lmcma_class_device_update_mode(oracle, use_cov):
     opt.close()
 
 
+def test_sepcma_class_follows_the_oracle_generation_by_generation(oracle):
+    """SepCMA behind the reference's interface: device sampling from the reference's RNG stream
+    (fp32 rows), host update; the oracle is handed the device's rows each generation."""
+    from lmcma_path_planner_amd import SepCMA
+    n, lam, seed = 24, 16, 9
+    lo, hi = np.full(n, -4.0), np.full(n, 6.0)
+    scale = 10.0 ** (np.arange(n) / (n - 1))
+    opt = SepCMA(np.full(n, 3.0), lam, lo, hi, 1.5, None, seed)
+    opt.init(n)
+    ref = oracle.OracleSepCMA(n, lam, initial=np.full(n, 3.0), lo=lo, hi=hi, sigma=1.5, seed=seed)
+    for g in range(60):
+        rows = opt.population()
+        assert np.max(np.abs(rows - ref.arx)) <= 2e-6 * (np.abs(ref.arx).max() + 1.0), g
+        costs = np.sum(scale * (rows - 1.0) ** 2, axis=1)
+        for i in range(lam):
+            x = opt.getNextParameterVector()
+            np.testing.assert_array_equal(x, rows[i])
+            opt.setEvaluationFeedback([costs[i]])
+        ref.set_arx(rows)
+        ref.tell_all(costs)
+        np.testing.assert_allclose(opt.mean(), ref.xmean, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(opt.sigma, ref.sigma, rtol=1e-12)
+        np.testing.assert_allclose(opt.diagonal(), ref.diag, rtol=1e-12)
+    assert opt.generation == 60 and opt.counteval == 60 * lam
+    assert opt.BestF < 1e-2 * np.sum(scale * 4.0)
+    opt.close()
+
+
+def test_sepcma_class_plans_on_the_device_cost(oracle):
+    from lmcma_path_planner_amd import SepCMA, grids
+    prob = grids.benchmark_problem(1)
+    co = oracle.CostOracle(2, prob.W, prob.occ, prob.start, prob.goal)
+    straight, _ = co.cost(prob.x0)
+    opt = SepCMA(prob.x0, 32, prob.lo, prob.hi, prob.sigma0, None, 42)
+    opt.setTrajectoryProblem(2, prob.W, prob.occ, prob.start, prob.goal)
+    opt.init(prob.N)
+    opt.step(300)
+    final, _ = co.cost(opt.mean())
+    assert opt.counteval == 300 * 32 and final < straight and opt.BestF < straight
+    opt.close()
+
+
 def test_error_reporting(hip):
     from lmcma_path_planner_amd._lib import LmcmaError
     with pytest.raises(LmcmaError, match="n_params"):

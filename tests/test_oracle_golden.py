@@ -174,3 +174,15 @@ def test_grid_generators(oracle):
     yy, xx = np.mgrid[0:12, 0:17]
     brute = np.sqrt(((yy[..., None] - ys) ** 2 + (xx[..., None] - xs) ** 2).min(axis=-1))
     np.testing.assert_allclose(oracle.edt_exact(small), brute.astype(np.float32), rtol=1e-6)
+
+
+def test_sepcma_restatement_converges_on_an_ellipsoid(oracle):
+    """SepCMA (lmcma.cpp:466-577) has no recorded reference output: parity unpinned beyond the
+    restated arithmetic; this only checks that the restatement optimises."""
+    n = 10
+    scale = np.arange(1, n + 1, dtype=np.float64)
+    s = oracle.OracleSepCMA(n, 12, initial=np.full(n, 3.0), sigma=1.0, seed=5)
+    assert s.lam == 12 and np.all(s.diag == 1.0)
+    for _ in range(300):
+        s.tell_all(np.sum(scale * (s.arx - 1.0) ** 2, axis=1))
+    assert np.abs(s.xmean - 1.0).max() < 1e-9 and s.sigma < 1e-6
