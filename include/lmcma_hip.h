@@ -219,7 +219,9 @@ int lmcma_hip_opt_get(lmcma_hip_ctx *ctx, lmcma_hip_opt_summary *summary,
                       double *xmean /* [N] or NULL */);
 /* full fp64 state for parity checks; any pointer may be NULL.
  * v_arr/pc_arr: [m][N] slot-indexed like the reference; nj/lj: [m];
- * iterator: [m]; pc: [N]                                                       */
+ * iterator: [m]; pc: [N].  Read it between generations: from phase_local to
+ * phase_update of one generation part of the direction store is already that
+ * of the next state (the rebuild of the older vectors runs beside the ranking). */
 int lmcma_hip_opt_get_vectors(lmcma_hip_ctx *ctx, double *pc, double *v_arr,
                               double *pc_arr, double *nj, double *lj,
                               int32_t *iterator);
