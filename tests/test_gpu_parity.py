@@ -728,8 +728,12 @@ def test_two_shards_on_one_gpu_match_the_unsharded_population(hip):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("G,mode", [(4, "ties"), (8, "random"), (3, "random")])
-def test_merged_ranks_of_shards_equal_the_stable_sort_of_the_whole_population(hip, G, mode):
+@pytest.mark.parametrize("G,mode,nloc", [(4, "ties", 256), (8, "random", 256), (3, "random", 256),
+                                         (8, "random", 4096),     # the 8-GPU job of bench.py: 32768 keys, one LDS chunk
+                                         (8, "random", 8192),     # 65536 keys: two chunks of four lists
+                                         (4, "random", 16384),    # 65536 keys: lists as long as half a chunk
+                                         (2, "ties", 4096)])
+def test_merged_ranks_of_shards_equal_the_stable_sort_of_the_whole_population(hip, G, mode, nloc):
     """G shards on one GPU; after the hand-made exchange of the sorted local costs every
     shard's entries of the global permutation and sorted list must be those of a stable
     sort of all costs in candidate order.  "ties": degenerate bounds make every candidate
@@ -739,7 +743,6 @@ def test_merged_ranks_of_shards_equal_the_stable_sort_of_the_whole_population(hi
     from lmcma_path_planner_amd import dist as shard_mod
     from lmcma_path_planner_amd import grids
     prob = grids.benchmark_problem(2)
-    nloc = 256
     lam = G * nloc
     dev = torch.device("cuda", 0)
     lo, hi = (prob.x0, prob.x0) if mode == "ties" else (prob.lo, prob.hi)
