@@ -796,6 +796,19 @@ def test_merged_ranks_of_shards_equal_the_stable_sort_of_the_whole_population(hi
         c.close()
 
 
+def test_sharded_generation_over_two_processes():
+    """dist.sharded_generation as bench.py --gpus 2 runs it, two ranks on this one GPU (gloo: RCCL
+    refuses two ranks on one device), against the unsharded population."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29517", os.path.join(here, "gpu_shard_worker.py"), "12"]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=110)
+    assert out.returncode == 0 and "sharded vs whole: equal" in out.stdout, out.stdout[-2000:]
+
+
 def test_cpp_examples_against_the_drop_in_header():
     """examples/*.cpp are written against include/lmcma.hpp like a caller of the reference's
     header; the binaries are built on the CPU box by __graft_entry__.build()."""
