@@ -355,24 +355,19 @@ struct RankMergeArgs {
 
 constexpr int kMergeChunk = 32768;  // keys in LDS at a time (128 KiB)
 
-// number of entries of the ascending key list s[0..n) that are below x (or_equal: at or below),
-// found by the 16 lanes of a group together; every lane returns the count
-__device__ __forceinline__ int group_search16(const uint32_t *s, int n, uint32_t x, bool or_equal, int lane, int shift)
+// number of entries of the ascending key list s[0..n) that are below x (or_equal: at or below):
+// a binary search by one lane.  The 16 lanes of a group each take one of the searches their
+// element needs (a list each), so a search costs a dozen dependent LDS reads but no
+// cross-lane traffic.
+__device__ __forceinline__ int count_below(const uint32_t *s, int n, uint32_t x, bool or_equal)
 {
-    int lo = 0, len = n;  // the answer lies in [lo, lo + len]
+    int lo = 0, len = n;
     while (len > 0) {
-        const int chunk = (len + 15) >> 4;
-        const int p = lo + (lane + 1) * chunk - 1;
-        bool hit = false;
-        if (p < lo + len) {
-            const uint32_t k = s[p];
-            hit = or_equal ? k <= x : k < x;
-        }
-        const unsigned long long mask = __ballot(hit);
-        const int q = __popcll((mask >> shift) & 0xFFFFull);  // probes below, of this group's 16
-        const int end = lo + len;
-        lo += q * chunk;
-        len = chunk - 1 < end - lo ? chunk - 1 : end - lo;
+        const int half = len >> 1;
+        const uint32_t k = s[lo + half];
+        const bool go = or_equal ? k <= x : k < x;
+        lo = go ? lo + half + 1 : lo;
+        len = go ? len - half - 1 : half;
     }
     return lo;
 }
@@ -393,6 +388,10 @@ __global__ __launch_bounds__(TB) void k_rank_merge(const RankMergeArgs r)
     uint32_t *s_below = reinterpret_cast<uint32_t *>(s_cand + CPB);  // [TB / 64]
     uint32_t *s_key = s_below + 16;                       // [min(lambda, kMergeChunk)]
 
+#ifdef LMCMA_DIAG
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    RANK_STAMP(0);
     const int p = blockIdx.x * CPB + grp;                 // local position of this group's element
     const bool live = p < nl;
     const int pc = live ? p : nl - 1;
@@ -401,42 +400,51 @@ __global__ __launch_bounds__(TB) void k_rank_merge(const RankMergeArgs r)
     const int cand = r.local_perm[pc];
 
     const int lists_per_chunk = kMergeChunk / nl > 0 ? kMergeChunk / nl : 1;  // n_local <= kMergeChunk
-    int rank = pc, at_or_below_prev = 0;
+    int rank = lane == 0 ? pc : 0, at_or_below_prev = 0;  // summed over the group's lanes after the searches
     uint32_t kmin = ~0u;
     {
         for (int g0 = 0; g0 < G; g0 += lists_per_chunk) {
             const int ng = G - g0 < lists_per_chunk ? G - g0 : lists_per_chunk;
             const int n4 = (ng * nl + 3) >> 2, base4 = (g0 * nl) >> 2;  // n_local is a multiple of 4
             __syncthreads();  // the previous chunk has been searched
-            for (int t0 = tid; t0 < n4; t0 += 8 * TB) {
-                uint4 kk[8];
-                {
-                    float4 c[8];
+            constexpr int kInFlight = TB <= 512 ? 16 : 8;  // 16-byte loads per thread before the first wait
+            for (int t0 = tid; t0 < n4; t0 += kInFlight * TB) {
+                float4 c[kInFlight];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int t = t0 + u * TB;
-                        c[u] = reinterpret_cast<const float4 *>(r.lists)[base4 + (t < n4 ? t : n4 - 1)];
-                    }
-                    asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        kk[u] = make_uint4(order_bits(c[u].x), order_bits(c[u].y), order_bits(c[u].z), order_bits(c[u].w));
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < kInFlight; ++u) {
                     const int t = t0 + u * TB;
-                    if (t < n4) reinterpret_cast<uint4 *>(s_key)[t] = kk[u];
+                    c[u] = reinterpret_cast<const float4 *>(r.lists)[base4 + (t < n4 ? t : n4 - 1)];
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < kInFlight; ++u) {
+                    const int t = t0 + u * TB;
+                    if (t < n4)
+                        reinterpret_cast<uint4 *>(s_key)[t] =
+                            make_uint4(order_bits(c[u].x), order_bits(c[u].y), order_bits(c[u].z), order_bits(c[u].w));
                 }
             }
             __syncthreads();
-            for (int g = g0; g < g0 + ng; ++g) {
-                const uint32_t *s = s_key + (size_t)(g - g0) * nl;
-                if (blockIdx.x == 0 && tid == 0) kmin = min(kmin, s[0]);  // a list's first entry is its lowest
-                if (g != r.me) rank += group_search16(s, nl, mine, g < r.me, lane, tid & 48);
-                if (psr) at_or_below_prev += group_search16(s, nl, yprev, true, lane, tid & 48);
+            RANK_STAMP(1);
+            if (blockIdx.x == 0 && tid == 0)
+                for (int g = 0; g < ng; ++g) kmin = min(kmin, s_key[(size_t)g * nl]);  // a list's first entry is its lowest
+            // searches of this element in the chunk: its own cost in every other list (ties across
+            // contexts resolve by context order: lists before this context's count their equal keys),
+            // and, for the success rule, its previous cost in every list; lane j takes searches j, j + 16, ...
+            const int nsearch = psr ? 2 * ng : ng;
+            for (int j = lane; j < nsearch; j += 16) {
+                const bool prev = j >= ng;
+                const int gl = prev ? j - ng : j, g = g0 + gl;
+                const uint32_t *s = s_key + (size_t)gl * nl;
+                if (prev) at_or_below_prev += count_below(s, nl, yprev, true);
+                else if (g != r.me) rank += count_below(s, nl, mine, g < r.me);
             }
         }
     }
+    // every lane of the group gets the sums over its 16 lanes
+    rank = (int)row16_sum_u32((uint32_t)rank);
+    at_or_below_prev = (int)row16_sum_u32((uint32_t)at_or_below_prev);
+    RANK_STAMP(2);
     const float value = order_bits_inv(mine);
     // pairs (this context's previous element, any current cost above it)
     uint32_t bsum = (psr && live && lane == 0) ? (uint32_t)(lambda - at_or_below_prev) : 0u;
@@ -447,6 +455,7 @@ __global__ __launch_bounds__(TB) void k_rank_merge(const RankMergeArgs r)
         s_cand[grp] = cand;
     }
     __syncthreads();
+    RANK_STAMP(3);
     uint32_t below_total = 0;
     if (tid == 0) {
 #pragma unroll
@@ -490,6 +499,11 @@ __global__ __launch_bounds__(TB) void k_rank_merge(const RankMergeArgs r)
         r.psr_parts[blockIdx.x] = below_total;
         if (blockIdx.x == 0) *r.best_out = order_bits_inv(kmin);
     }
+#ifdef LMCMA_DIAG
+    RANK_STAMP(4);
+    if (tid == 0 && blockIdx.x == gridDim.x - 1)
+        for (int q = 0; q < 5; ++q) g_update_stamps[8 + q] = st[q];
+#endif
 }
 
 template <int TB>
