@@ -17,7 +17,8 @@
 //
 // SepCMA (reference lmcma.hpp:152-190) is provided with the same division of work:
 // sampling (and, with a trajectory problem, scoring) on the GPU, its O(mu N) update on the
-// host.  CMAChol (reference lmcma.hpp:199-239) is not provided.
+// host.  CMAChol (reference lmcma.hpp:199-239) likewise: its dense product A z runs on
+// the matrix cores, its O(N^2) factor update on the host.
 #ifndef LMCMA_AMD_LMCMA_HPP
 #define LMCMA_AMD_LMCMA_HPP
 
@@ -157,6 +158,44 @@ public:
 private:
     SepCMA(const SepCMA &);
     SepCMA &operator=(const SepCMA &);
+    Impl *impl;
+};
+
+// Cholesky-CMA-ES (reference lmcma.hpp:199-239, lmcma.cpp:579-754): a dense factor A of the
+// covariance, updated by a rank-one step per generation.  Candidates x = xmean + sigma A z:
+// the normals come from the reference's sequential generator, the product A z (lambda N^2
+// multiply-adds, lmcma.cpp:649-664) runs on the device; CMAChol::update and CholeskyUpdate
+// (lmcma.cpp:666-754) run on the host in fp64 in the reference's order of operations.
+class CMAChol : public CMABase {
+public:
+    CMAChol(double *initialParams, int lambda = 0, double *loBounds = 0, double *hiBounds = 0,
+            double sigma = 1.0, double *covariance = 0, int inseed = 0, bool verbose = false);
+    ~CMAChol();
+    void init(int N);
+    void getNextParameterVector(double *params, int N);
+    void setEvaluationFeedback(double *feedbacks, int numFeedbacks);
+    void sample();
+    void update();
+
+    // ---- extensions, as for LMCMA ---------------------------------------------------
+    void setDevice(int ordinal);
+    void setTrajectoryProblem(const LMCMATrajectoryProblem &problem);
+    void evaluatePopulation();
+    void step(int generations = 1) { for (int g = 0; g < generations; ++g) evaluatePopulation(); }
+    int dimension() const;
+    int populationSize() const;
+    int generation() const;
+    double stepSize() const;
+    void mean(double *xmean_out) const;       // [N]
+    void factor(double *A_out) const;         // [N][N] row-major, A A^T = covariance
+    void population(double *rows_out) const;  // [lambda][N]
+
+    struct Impl;
+
+private:
+    CMAChol(const CMAChol &);
+    CMAChol &operator=(const CMAChol &);
+    void CholeskyUpdate(double *pc, double *Ainv, double *A);
     Impl *impl;
 };
 

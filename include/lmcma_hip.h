@@ -119,13 +119,16 @@ int lmcma_hip_set_state(lmcma_hip_ctx *ctx, const double *xmean, double sigma,
                         const double *V, const double *PC, const double *nj,
                         int k, double M);
 
-/* The `covariance` argument of the constructor (L/lmcma.hpp:131-133) after
- * cholesky() (L/lmcma.cpp:165-169, 844-855): L[c*N + r] = Lm(r, c), the lower
- * factor column-major.  With it every candidate's Philox normals become
- * z <- Lm z before the low-rank transform, as sampleStandardNormal + applyCovL
- * do (L/lmcma.cpp:212-218, 857-864); the product runs in fp32 on the matrix
- * cores.  NULL returns to the identity.  z_source PHILOX only: a caller that
- * draws its own normals (z_source HOST) applies the factor itself.             */
+/* A factor applied to every candidate's normals before the low-rank transform:
+ * z <- Lm z, in fp32 on the matrix cores.  L[c*N + r] = Lm(r, c), i.e. Lm
+ * column-major: the layout cholesky() leaves the factor of the constructor's
+ * `covariance` argument in (L/lmcma.hpp:131-133, L/lmcma.cpp:165-169, 844-855),
+ * which sampleStandardNormal + applyCovL apply the same way (:212-218,
+ * 857-864); any dense matrix is accepted (CMAChol::sample multiplies by its
+ * full factor A, L/lmcma.cpp:649-664).  NULL returns to the identity.  The
+ * factor applies to device-drawn normals (z_source PHILOX) and to normals
+ * handed to lmcma_hip_sample alike; a caller that has applied its factor on
+ * the host simply does not set one.                                            */
 int lmcma_hip_set_cov_factor(lmcma_hip_ctx *ctx, const double *L);
 
 /* LMCMA::sample (L/lmcma.cpp:301-311) for this context's candidates.

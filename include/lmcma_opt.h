@@ -30,6 +30,9 @@ int lmcma_opt_create(const double *initial, const double *lo, const double *hi, 
  * separable CMA-ES through the functions below (set_options: only `device` applies).  */
 int lmcma_opt_create_sep(const double *initial, const double *lo, const double *hi, const double *cov,
                          int n, int lambda, double sigma, int seed, int verbose, lmcma_opt **out);
+/* CMAChol::CMAChol (L/lmcma.hpp:231-233), likewise */
+int lmcma_opt_create_chol(const double *initial, const double *lo, const double *hi, const double *cov,
+                          int n, int lambda, double sigma, int seed, int verbose, lmcma_opt **out);
 int lmcma_opt_destroy(lmcma_opt *o);
 
 /* extensions of include/lmcma.hpp; call before lmcma_opt_init.  m < 1: lambda */
@@ -61,6 +64,8 @@ int lmcma_opt_get_population(lmcma_opt *o, double *rows);
 int lmcma_opt_get_last_costs(lmcma_opt *o, double *costs);
 /* SepCMA handles: diagD (L/lmcma.hpp:158), the square roots of the diagonal covariance */
 int lmcma_opt_get_diagonal(lmcma_opt *o, double *diag_d);
+/* CMAChol handles: the factor A (L/lmcma.hpp:202), [N][N] row-major */
+int lmcma_opt_get_factor(lmcma_opt *o, double *a_rowmajor);
 
 /* ---- host helpers ---------------------------------------------------------------- */
 

@@ -114,6 +114,8 @@ SIGNATURES = {
                               ctypes.POINTER(_vp)]),
     "lmcma_opt_create_sep": (_i, [c_double_p, c_double_p, c_double_p, c_double_p, _i, _i, ctypes.c_double, _i, _i,
                                   ctypes.POINTER(_vp)]),
+    "lmcma_opt_create_chol": (_i, [c_double_p, c_double_p, c_double_p, c_double_p, _i, _i, ctypes.c_double, _i, _i,
+                                   ctypes.POINTER(_vp)]),
     "lmcma_opt_destroy": (_i, [_vp]),
     "lmcma_opt_set_options": (_i, [_vp, _i, _i, _i, _i]),
     "lmcma_opt_set_problem": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_double, c_double_p, c_double_p,
@@ -128,6 +130,7 @@ SIGNATURES = {
     "lmcma_opt_get_population": (_i, [_vp, c_double_p]),
     "lmcma_opt_get_last_costs": (_i, [_vp, c_double_p]),
     "lmcma_opt_get_diagonal": (_i, [_vp, c_double_p]),
+    "lmcma_opt_get_factor": (_i, [_vp, c_double_p]),
     "lmcma_host_gauss_stream": (_i, [_i, _i, c_double_p]),
     "lmcma_host_uniform_stream": (_i, [_i, _i, c_double_p]),
     "lmcma_host_covariance": (_i, [_i, _i, c_double_p]),

@@ -259,10 +259,9 @@ CostParams cost_params(const lmcma_hip_ctx *c, const float *rows, int n_rows, fl
 int do_sample(lmcma_hip_ctx *c, const float *z)
 {
     Timed tm(c, LMCMA_K_SAMPLE);
-    // normals handed in by the caller already carry the factor (sampleStandardNormal applies it
-    // where it draws them, L/lmcma.cpp:212-218)
+    // a factor set on the context applies to the normals of either source
     HIP_TRY(launch_sample(c->stream, c->rows, z, c->xmean_f, c->V_f, c->B_f, c->lo_f, c->hi_f, c->sc,
-                          c->ld, c->nloc, (uint32_t)c->first, c->cfg.seed, (c->have_cov && !z) ? &c->cov : nullptr));
+                          c->ld, c->nloc, (uint32_t)c->first, c->cfg.seed, c->have_cov ? &c->cov : nullptr));
     c->sampled = true;
     return LMCMA_HIP_OK;
 }
@@ -785,8 +784,6 @@ int lmcma_hip_set_cov_factor(lmcma_hip_ctx *c, const double *L)
         c->have_cov = false;
         return LMCMA_HIP_OK;
     }
-    if (c->cfg.z_source != LMCMA_Z_PHILOX)
-        return fail(LMCMA_HIP_ERR_STATE, "set_cov_factor: with z_source HOST the caller applies the factor to its normals");
     const int N = c->N, nt = (std::max(N, c->ld) + 15) / 16, np = 16 * nt;
     if (nt > 32) return fail(LMCMA_HIP_ERR_UNSUPPORTED, "set_cov_factor: N up to 512");
     std::vector<float> lf((size_t)np * np, 0.f);

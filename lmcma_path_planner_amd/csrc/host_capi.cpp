@@ -36,9 +36,15 @@ int guarded(F &&f)
 struct lmcma_opt {
     std::vector<double> initial, lo, hi, cov;
     LMCMA *opt = nullptr;
-    SepCMA *sep = nullptr;   // a handle holds one of the two optimisers
-    ~lmcma_opt() { delete opt; delete sep; }
-    CMABase *base() { return opt ? static_cast<CMABase *>(opt) : static_cast<CMABase *>(sep); }
+    SepCMA *sep = nullptr;   // a handle holds one of the three optimisers
+    CMAChol *chol = nullptr;
+    ~lmcma_opt() { delete opt; delete sep; delete chol; }
+    CMABase *base()
+    {
+        if (opt) return opt;
+        if (sep) return sep;
+        return chol;
+    }
 };
 
 extern "C" {
@@ -77,6 +83,22 @@ int lmcma_opt_create_sep(const double *initial, const double *lo, const double *
     });
 }
 
+int lmcma_opt_create_chol(const double *initial, const double *lo, const double *hi, const double *cov,
+                          int n, int lambda, double sigma, int seed, int verbose, lmcma_opt **out)
+{
+    if (!out || n < 1) { g_err = "lmcma_opt_create_chol: bad arguments"; return -1; }
+    return guarded([&] {
+        lmcma_opt *h = new lmcma_opt();
+        if (initial) h->initial.assign(initial, initial + n);
+        if (lo) h->lo.assign(lo, lo + n);
+        if (hi) h->hi.assign(hi, hi + n);
+        if (cov) h->cov.assign(cov, cov + (size_t)n * n);
+        h->chol = new CMAChol(initial ? h->initial.data() : 0, lambda, lo ? h->lo.data() : 0,
+                              hi ? h->hi.data() : 0, sigma, cov ? h->cov.data() : 0, seed, verbose != 0);
+        *out = h;
+    });
+}
+
 int lmcma_opt_destroy(lmcma_opt *o)
 {
     return guarded([&] { delete o; });
@@ -86,9 +108,10 @@ int lmcma_opt_set_options(lmcma_opt *o, int m, int device, int philox, int devic
 {
     if (!o) { g_err = "null handle"; return -1; }
     return guarded([&] {
-        if (o->sep) {
-            if (philox || device_update) throw std::invalid_argument("SepCMA: host normals and host update only");
-            o->sep->setDevice(device);
+        if (!o->opt) {
+            if (philox || device_update) throw std::invalid_argument("SepCMA / CMAChol: host normals and host update only");
+            if (o->sep) o->sep->setDevice(device);
+            else o->chol->setDevice(device);
             return;
         }
         o->opt->setDirectionVectors(m);
@@ -118,6 +141,7 @@ int lmcma_opt_set_problem(lmcma_opt *o, int dims, int waypoints, int nx, int ny,
         p.w_len = w_len; p.w_grid = w_grid; p.w_smooth = w_smooth;
         p.pad_mode = pad_mode;
         if (o->sep) o->sep->setTrajectoryProblem(p);
+        else if (o->chol) o->chol->setTrajectoryProblem(p);
         else o->opt->setTrajectoryProblem(p);
     });
 }
@@ -153,6 +177,7 @@ int lmcma_opt_step(lmcma_opt *o, int generations)
     if (!o) { g_err = "null handle"; return -1; }
     return guarded([&] {
         if (o->sep) o->sep->step(generations);
+        else if (o->chol) o->chol->step(generations);
         else o->opt->step(generations);
     });
 }
@@ -171,6 +196,16 @@ int lmcma_opt_get_info(lmcma_opt *o, lmcma_opt_info *info)
             info->sigma = o->sep->stepSize();
             return;
         }
+        if (o->chol) {
+            info->n = o->chol->dimension();
+            info->lambda = o->chol->populationSize();
+            info->m = 0;
+            info->generation = o->chol->generation();
+            info->counteval = o->chol->counteval;
+            info->best_f = o->chol->BestF;
+            info->sigma = o->chol->stepSize();
+            return;
+        }
         info->n = o->opt->dimension();
         info->lambda = o->opt->populationSize();
         info->m = o->opt->directionVectors();
@@ -186,6 +221,7 @@ int lmcma_opt_get_mean(lmcma_opt *o, double *xmean)
     if (!o || !xmean) { g_err = "null argument"; return -1; }
     return guarded([&] {
         if (o->sep) o->sep->mean(xmean);
+        else if (o->chol) o->chol->mean(xmean);
         else o->opt->mean(xmean);
     });
 }
@@ -195,6 +231,7 @@ int lmcma_opt_get_population(lmcma_opt *o, double *rows)
     if (!o || !rows) { g_err = "null argument"; return -1; }
     return guarded([&] {
         if (o->sep) o->sep->population(rows);
+        else if (o->chol) o->chol->population(rows);
         else o->opt->population(rows);
     });
 }
@@ -205,6 +242,15 @@ int lmcma_opt_get_last_costs(lmcma_opt *o, double *costs)
     return guarded([&] {
         if (!o->opt) throw std::invalid_argument("last costs are kept by LMCMA handles only");
         o->opt->lastCosts(costs);
+    });
+}
+
+int lmcma_opt_get_factor(lmcma_opt *o, double *a_rowmajor)
+{
+    if (!o || !a_rowmajor) { g_err = "null argument"; return -1; }
+    return guarded([&] {
+        if (!o->chol) throw std::invalid_argument("only CMAChol handles have a factor");
+        o->chol->factor(a_rowmajor);
     });
 }
 

@@ -159,6 +159,20 @@ class SepCMA(LMCMA):
         return out
 
 
+class CMAChol(LMCMA):
+    """Cholesky-CMA-ES with the reference's interface (lmcma.hpp:199-239); the dense product A z and,
+    with a trajectory problem, scoring on the device, the factor update on the host."""
+    _create = "lmcma_opt_create_chol"
+
+    def setOptions(self, device=0):
+        check_opt(self.lib.lmcma_opt_set_options(self._h, 0, int(device), 0, 0), "lmcma_opt_set_options")
+
+    def factor(self):
+        out = np.empty((self.N, self.N), dtype=np.float64)
+        check_opt(self.lib.lmcma_opt_get_factor(self._h, _dp(out)), "lmcma_opt_get_factor")
+        return out
+
+
 # ---- host helpers (reference free functions) ----------------------------------------------
 
 def gauss_stream(seed, n):

@@ -1182,3 +1182,153 @@ double orc_sep_sigma(const orc_sep *o) { return o->sigma; }
 const double *orc_sep_arx(const orc_sep *o) { return o->arx; }
 const double *orc_sep_xmean(const orc_sep *o) { return o->xmean; }
 const double *orc_sep_diag(const orc_sep *o) { return o->diagD; }
+
+/* ---- Cholesky-CMA-ES: CMAChol of L/lmcma.hpp:199-239, L/lmcma.cpp:579-754 ------------ */
+struct orc_chol {
+    int N, lambda, mu, itr;
+    double mueff, sigma, cc, c1, chiN, cs, damps;
+    double *weights, *xmean, *xold, *arx, *arz, *arfitness, *A, *Ainv, *pc, *ps, *zmean, *tmp1, *tmp2, *lo, *hi, *L;
+    int *arindex;
+    orc_rng rng;
+};
+
+static void chol_sample(orc_chol *o)
+{
+    /* L/lmcma.cpp:649-664 */
+    int N = o->N;
+    for (int i = 0; i < o->lambda; ++i) {
+        double *z = &o->arz[(size_t)i * N];
+        for (int n = 0; n < N; ++n) z[n] = orc_rng_gauss(&o->rng);
+        if (o->L) orc_apply_cov_l(o->L, z, N);
+        for (int k = 0; k < N; ++k) {
+            double Az = 0;
+            for (int p = 0; p < N; ++p) Az += o->A[(size_t)k * N + p] * z[p];
+            o->arx[(size_t)i * N + k] = o->xmean[k] + o->sigma * Az;
+        }
+    }
+    for (int i = 0; i < o->lambda; ++i)
+        for (int k = 0; k < N; ++k) {
+            double *x = &o->arx[(size_t)i * N + k];
+            if (o->lo) *x = fmax(*x, o->lo[k]);
+            if (o->hi) *x = fmin(*x, o->hi[k]);
+        }
+}
+
+orc_chol *orc_chol_create(int N, int lambda, const double *initial, const double *lo, const double *hi,
+                          double sigma, const double *cov, long seed)
+{
+    orc_chol *o = (orc_chol *)calloc(1, sizeof(orc_chol));
+    o->N = N;
+    orc_rng_start(&o->rng, (unsigned long)seed);
+    if (lambda < 1) lambda = 4 + (int)(3 * log((double)N));
+    o->lambda = lambda;
+    o->mu = lambda / 2;
+    o->weights = (double *)calloc((size_t)(o->mu > 0 ? o->mu : 1), sizeof(double));
+    o->xmean = (double *)calloc((size_t)N, sizeof(double));
+    o->xold = (double *)calloc((size_t)N, sizeof(double));
+    if (initial) for (int i = 0; i < N; ++i) o->xmean[i] = initial[i];
+    else for (int i = 0; i < N; ++i) o->xmean[i] = orc_rng_uniform(&o->rng);
+    o->lo = dup_d(lo, N);
+    o->hi = dup_d(hi, N);
+    if (cov) {
+        o->L = (double *)calloc((size_t)N * N, sizeof(double));
+        orc_cholesky(cov, o->L, N);
+    }
+    o->sigma = sigma;
+    o->arx = (double *)calloc((size_t)N * lambda, sizeof(double));
+    o->arz = (double *)calloc((size_t)N * lambda, sizeof(double));
+    o->arfitness = (double *)calloc((size_t)lambda, sizeof(double));
+    o->arindex = (int *)calloc((size_t)lambda, sizeof(int));
+    o->A = (double *)calloc((size_t)N * N, sizeof(double));
+    o->Ainv = (double *)calloc((size_t)N * N, sizeof(double));
+    o->pc = (double *)calloc((size_t)N, sizeof(double));
+    o->ps = (double *)calloc((size_t)N, sizeof(double));
+    o->zmean = (double *)calloc((size_t)N, sizeof(double));
+    o->tmp1 = (double *)calloc((size_t)N, sizeof(double));
+    o->tmp2 = (double *)calloc((size_t)N, sizeof(double));
+    /* L/lmcma.cpp:608-645 */
+    double sum_weights = 0;
+    for (int i = 0; i < o->mu; ++i) sum_weights += log(i + 1.0);
+    for (int i = 0; i < o->mu; ++i) {
+        o->weights[i] = (log((double)(o->mu + 1.0)) - log((double)(1.0 + i))) / (o->mu * log(o->mu + 1.0) - sum_weights);
+        o->mueff += o->weights[i] * o->weights[i];
+    }
+    o->mueff = 1.0 / o->mueff;
+    for (int i = 0; i < N; ++i) o->A[(size_t)i * N + i] = o->Ainv[(size_t)i * N + i] = 1;
+    o->cc = 4.0 / (N + 4.0);
+    o->c1 = 2.0 / pow(N + sqrt(2.0), 2.0);
+    o->chiN = sqrt((double)N) * (1.0 - (1.0 / (4.0 * (double)N)) + (1.0 / (21.0 * (double)(N * N))));
+    o->cs = sqrt(o->mueff) / (sqrt((double)N) + sqrt(o->mueff));
+    o->damps = 1.0 + 2.0 * fmax(0.0, sqrt((o->mueff - 1.0) / (N + 1.0)) - 1.0) + o->cs;
+    chol_sample(o);
+    return o;
+}
+
+void orc_chol_destroy(orc_chol *o)
+{
+    if (!o) return;
+    free(o->weights); free(o->xmean); free(o->xold); free(o->arx); free(o->arz); free(o->arfitness);
+    free(o->A); free(o->Ainv); free(o->pc); free(o->ps); free(o->zmean); free(o->tmp1); free(o->tmp2);
+    free(o->lo); free(o->hi); free(o->L); free(o->arindex);
+    free(o);
+}
+
+static void chol_factor_update(orc_chol *o)
+{
+    /* CholeskyUpdate, L/lmcma.cpp:703-754 */
+    int N = o->N;
+    double *v = o->tmp1, *w = o->tmp2;
+    const double alpha = 1 - o->c1, sqrtAlpha = sqrt(alpha), gamma = o->c1;
+    for (int i = 0; i < N; ++i) {
+        v[i] = 0.0;
+        for (int j = 0; j < N; ++j) v[i] += o->Ainv[(size_t)i * N + j] * o->pc[j];
+    }
+    double norm_v2 = 0.0;
+    for (int i = 0; i < N; ++i) norm_v2 += v[i] * v[i];
+    const double tmp_root = sqrt(1.0 + (gamma / alpha) * norm_v2);
+    const double k1 = sqrtAlpha, k2 = sqrtAlpha / norm_v2 * (tmp_root - 1.0);
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) o->A[(size_t)i * N + j] = k1 * o->A[(size_t)i * N + j] + k2 * o->pc[i] * v[j];
+    for (int i = 0; i < N; ++i) {
+        w[i] = 0.0;
+        for (int j = 0; j < N; ++j) w[i] += v[j] * o->Ainv[(size_t)j * N + i];
+    }
+    const double k3 = 1.0 / sqrtAlpha, k4 = (1.0 - 1.0 / tmp_root) / (sqrtAlpha * norm_v2);
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) o->Ainv[(size_t)i * N + j] = k3 * o->Ainv[(size_t)i * N + j] - k4 * v[i] * w[j];
+}
+
+/* one generation's feedback: CMAChol::update (L/lmcma.cpp:666-701), then sample */
+void orc_chol_tell_all(orc_chol *o, const double *fitness)
+{
+    int N = o->N, mu = o->mu;
+    memcpy(o->arfitness, fitness, (size_t)o->lambda * sizeof(double));
+    orc_sort(o->lambda, o->arfitness, o->arindex);
+    for (int i = 0; i < N; ++i) { o->xold[i] = o->xmean[i]; o->xmean[i] = 0; o->zmean[i] = 0; }
+    for (int i = 0; i < mu; ++i) {
+        const double *x = &o->arx[(size_t)o->arindex[i] * N], *z = &o->arz[(size_t)o->arindex[i] * N];
+        for (int j = 0; j < N; ++j) {
+            o->xmean[j] += o->weights[i] * x[j];
+            o->zmean[j] += o->weights[i] * z[j];
+        }
+    }
+    double norm_ps = 0;
+    for (int i = 0; i < N; ++i) {
+        o->ps[i] = (1 - o->cs) * o->ps[i] + sqrt(o->cs * (2 - o->cs) * o->mueff) * o->zmean[i];
+        norm_ps += o->ps[i] * o->ps[i];
+    }
+    norm_ps = sqrt(norm_ps);
+    for (int i = 0; i < N; ++i)
+        o->pc[i] = (1 - o->cc) * o->pc[i] + sqrt(o->cc * (2 - o->cc) * o->mueff) * (o->xmean[i] - o->xold[i]) / o->sigma;
+    chol_factor_update(o);
+    o->sigma *= exp((o->cs / o->damps) * (norm_ps / o->chiN - 1));
+    o->itr++;
+    chol_sample(o);
+}
+
+void orc_chol_set_arx(orc_chol *o, const double *rows) { memcpy(o->arx, rows, (size_t)o->lambda * o->N * sizeof(double)); }
+int orc_chol_lambda(const orc_chol *o) { return o->lambda; }
+double orc_chol_sigma(const orc_chol *o) { return o->sigma; }
+const double *orc_chol_arx(const orc_chol *o) { return o->arx; }
+const double *orc_chol_xmean(const orc_chol *o) { return o->xmean; }
+const double *orc_chol_factor(const orc_chol *o) { return o->A; }

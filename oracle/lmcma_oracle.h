@@ -158,6 +158,19 @@ const double *orc_sep_arx(const orc_sep *o);
 const double *orc_sep_xmean(const orc_sep *o);
 const double *orc_sep_diag(const orc_sep *o);
 
+/* ---- Cholesky-CMA-ES (CMAChol, L/lmcma.hpp:199-239, L/lmcma.cpp:579-754) ------------- */
+typedef struct orc_chol orc_chol;
+orc_chol *orc_chol_create(int N, int lambda, const double *initial, const double *lo, const double *hi,
+                          double sigma, const double *cov, long seed);
+void orc_chol_destroy(orc_chol *o);
+void orc_chol_tell_all(orc_chol *o, const double *fitness);
+void orc_chol_set_arx(orc_chol *o, const double *rows);
+int orc_chol_lambda(const orc_chol *o);
+double orc_chol_sigma(const orc_chol *o);
+const double *orc_chol_arx(const orc_chol *o);
+const double *orc_chol_xmean(const orc_chol *o);
+const double *orc_chol_factor(const orc_chol *o);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,16 @@ def load():
     for name in ("arx", "xmean", "diag"):
         f = getattr(L, "orc_sep_" + name)
         f.argtypes, f.restype = [vp], c_double_p
+    L.orc_chol_create.argtypes = [i, i, c_double_p, c_double_p, c_double_p, d, c_double_p, ctypes.c_long]
+    L.orc_chol_create.restype = vp
+    L.orc_chol_destroy.argtypes = [vp]
+    L.orc_chol_tell_all.argtypes = [vp, c_double_p]
+    L.orc_chol_set_arx.argtypes = [vp, c_double_p]
+    L.orc_chol_lambda.argtypes, L.orc_chol_lambda.restype = [vp], i
+    L.orc_chol_sigma.argtypes, L.orc_chol_sigma.restype = [vp], d
+    for name in ("arx", "xmean", "factor"):
+        f = getattr(L, "orc_chol_" + name)
+        f.argtypes, f.restype = [vp], c_double_p
     L.orc_lmcma_done.argtypes = [vp]
     for name in ("lambda", "mu", "m", "itr", "iterator_sz", "counteval"):
         f = getattr(L, "orc_lmcma_" + name)
@@ -226,6 +236,49 @@ class OracleSepCMA:
     @property
     def sigma(self):
         return self.L.orc_sep_sigma(self.h)
+
+
+class OracleCMAChol:
+    """The fp64 restatement of the reference's CMAChol (lmcma.cpp:579-754)."""
+
+    def __init__(self, N, lam=0, initial=None, lo=None, hi=None, sigma=1.0, cov=None, seed=42):
+        self.L = load()
+        self.N = N
+        init, lo, hi, cov = _f64(initial), _f64(lo), _f64(hi), _f64(cov)
+        self.h = self.L.orc_chol_create(N, lam, _dp(init), _dp(lo), _dp(hi), sigma, _dp(cov), seed)
+        self.lam = self.L.orc_chol_lambda(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_chol_destroy(self.h)
+            self.h = None
+
+    def tell_all(self, fitness):
+        self.L.orc_chol_tell_all(self.h, _dp(_f64(fitness)))
+
+    def set_arx(self, rows):
+        rows = _f64(rows)
+        assert rows.shape == (self.lam, self.N)
+        self.L.orc_chol_set_arx(self.h, _dp(rows))
+
+    def _arr(self, name, shape):
+        return np.ctypeslib.as_array(getattr(self.L, "orc_chol_" + name)(self.h), shape=shape).copy()
+
+    @property
+    def arx(self):
+        return self._arr("arx", (self.lam, self.N))
+
+    @property
+    def xmean(self):
+        return self._arr("xmean", (self.N,))
+
+    @property
+    def factor(self):
+        return self._arr("factor", (self.N, self.N))
+
+    @property
+    def sigma(self):
+        return self.L.orc_chol_sigma(self.h)
 
 
 class OracleLMCMA:

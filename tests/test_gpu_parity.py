@@ -638,6 +638,37 @@ def test_sepcma_class_plans_on_the_device_cost(oracle):
     opt.close()
 
 
+def test_cmachol_class_follows_the_oracle_generation_by_generation(oracle):
+    """CMAChol behind the reference's interface: normals from the reference's RNG stream, the dense
+    product A z on the device in fp32, the factor update on the host; the oracle is handed the
+    device's rows each generation."""
+    from lmcma_path_planner_amd import CMAChol
+    n, lam, seed = 40, 24, 4
+    lo, hi = np.full(n, -5.0), np.full(n, 7.0)
+    rng = np.random.default_rng(6)
+    Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    H = Q @ np.diag(10.0 ** np.linspace(0, 2, n)) @ Q.T
+    opt = CMAChol(np.full(n, 3.0), lam, lo, hi, 1.5, None, seed)
+    opt.init(n)
+    ref = oracle.OracleCMAChol(n, lam, initial=np.full(n, 3.0), lo=lo, hi=hi, sigma=1.5, seed=seed)
+    for g in range(80):
+        rows = opt.population()
+        scale = np.abs(ref.xmean).max() + np.abs(ref.arx - ref.xmean).max() + 1.0
+        assert np.max(np.abs(rows - ref.arx)) <= 1e-5 * scale, g
+        X = rows - 1.0
+        costs = np.einsum("ij,jk,ik->i", X, H, X)
+        for i in range(lam):
+            opt.getNextParameterVector()
+            opt.setEvaluationFeedback([costs[i]])
+        ref.set_arx(rows)
+        ref.tell_all(costs)
+        np.testing.assert_allclose(opt.mean(), ref.xmean, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(opt.sigma, ref.sigma, rtol=1e-12)
+        np.testing.assert_allclose(opt.factor(), ref.factor, rtol=1e-10, atol=1e-12)
+    assert opt.generation == 80 and opt.BestF < 0.1 * float(np.full(n, 2.0) @ H @ np.full(n, 2.0))
+    opt.close()
+
+
 def test_error_reporting(hip):
     from lmcma_path_planner_amd._lib import LmcmaError
     with pytest.raises(LmcmaError, match="n_params"):
@@ -662,11 +693,19 @@ def test_error_reporting(hip):
         ctx.set_cov_factor(np.full((64, 64), np.nan))
     assert 0.0 < ctx.timing_event_overhead(64) < 1.0   # milliseconds per empty event bracket
     ctx.close()
-    # normals drawn by the caller carry the factor already: the device does not take one
+    # a factor also applies to normals the caller hands in
+    rng = np.random.default_rng(2)
+    A = rng.normal(size=(64, 64)) / 8.0
+    Z = rng.normal(size=(16, 64))
     ctx = hip.HipContext(64, 16, 4, z_source=hip.Z_HOST, cost_source=hip.COST_EXTERNAL)
-    with pytest.raises(LmcmaError, match="z_source HOST"):
-        ctx.set_cov_factor(np.eye(64))
+    ctx.set_cov_factor(np.ascontiguousarray(A.T))            # L[c*N + r] = A(r, c)
+    ctx.set_state(np.zeros(64), 1.0, None, None, None, 1.0)
+    ctx.sample(0, Z)
+    want = Z.astype(np.float32).astype(np.float64) @ A.T
+    assert np.max(np.abs(ctx.rows() - want)) <= 1e-5 * np.abs(want).max()
     ctx.set_cov_factor(None)
+    ctx.sample(0, Z)
+    assert np.max(np.abs(ctx.rows() - Z)) <= 1e-6
     ctx.close()
 
 

@@ -186,3 +186,17 @@ def test_sepcma_restatement_converges_on_an_ellipsoid(oracle):
     for _ in range(300):
         s.tell_all(np.sum(scale * (s.arx - 1.0) ** 2, axis=1))
     assert np.abs(s.xmean - 1.0).max() < 1e-9 and s.sigma < 1e-6
+
+
+def test_cmachol_restatement_converges_on_a_rotated_ellipsoid(oracle):
+    """CMAChol (lmcma.cpp:579-754): parity unpinned like SepCMA; the restatement must optimise a
+    problem a diagonal model cannot (a rotated ellipsoid) and keep A A^-1 = I."""
+    n = 8
+    rng = np.random.default_rng(1)
+    Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    H = Q @ np.diag(10.0 ** np.linspace(0, 3, n)) @ Q.T
+    c = oracle.OracleCMAChol(n, 16, initial=np.full(n, 2.0), sigma=1.0, seed=3)
+    for _ in range(600):
+        X = c.arx - 1.0
+        c.tell_all(np.einsum("ij,jk,ik->i", X, H, X))
+    assert np.abs(c.xmean - 1.0).max() < 1e-6 and c.sigma < 1e-3
