@@ -865,6 +865,10 @@ def test_cpp_examples_against_the_drop_in_header():
     assert out.returncode == 0, out.stdout + out.stderr
     assert "generations 400 evaluations 25600" in out.stdout
     assert float(re.search(r"best cost ([0-9.]+)", out.stdout).group(1)) < 2000.0   # straight line: 25596
+    sib = os.path.join(root, "examples", "bin", "sibling_optimisers")
+    assert os.path.exists(sib), "run __graft_entry__.build() first"
+    out = subprocess.run([sib, "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
 
 
 def test_stepwise_api_with_the_reference_choice_m_equal_lambda(hip, oracle):
