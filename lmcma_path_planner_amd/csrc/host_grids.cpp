@@ -255,7 +255,7 @@ int lmcma_grid_read_binvox(const char *path, int dims[3], double translate[3], d
         else if (!strcmp(word, "scale")) { if (fscanf(f, "%lf", &sc) != 1) return -3; }
         else { int ch; while ((ch = fgetc(f)) != EOF && ch != '\n') {} }  // unknown keyword: skip its line
     }
-    if (!data || depth < 1 || height < 1 || width < 1) return -3;
+    if (!data || depth < 1 || height < 1 || width < 1 || depth > 65536 || height > 65536 || width > 65536) return -3;
     dims[0] = depth; dims[1] = width; dims[2] = height;  // extents along x, y, z
     if (translate) std::copy(t, t + 3, translate);
     if (scale) *scale = sc;
