@@ -104,7 +104,8 @@ public:
     // the costs back, which runs update() and sample() like the lambda-th
     // setEvaluationFeedback call does.
     void evaluatePopulation();
-    void step(int generations = 1) { for (int g = 0; g < generations; ++g) evaluatePopulation(); }
+    // `generations` of them; with the device update they run without a host round trip between them
+    void step(int generations = 1);
 
     // ---- state readers ----------------------------------------------------------------
     int dimension() const;

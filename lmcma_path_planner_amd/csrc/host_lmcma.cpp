@@ -590,13 +590,17 @@ void LMCMA::update()
     advanceState(d, sorted);
 }
 
-void LMCMA::evaluatePopulation()
+void LMCMA::evaluatePopulation() { step(1); }
+
+void LMCMA::step(int generations)
 {
     Impl &d = *impl;
-    if (!d.initialised) throw std::runtime_error("LMCMA::evaluatePopulation before init");
-    if (!d.haveProblem) throw std::runtime_error("evaluatePopulation needs setTrajectoryProblem");
+    if (!d.initialised) throw std::runtime_error("LMCMA::step before init");
+    if (!d.haveProblem) throw std::runtime_error("step needs setTrajectoryProblem");
+    if (generations < 1) return;
     if (d.deviceUpdate) {
-        d.hip(lmcma_hip_run(d.ctx, 1), "lmcma_hip_run");
+        // all of them in one call: the library replays captured generations back to back
+        d.hip(lmcma_hip_run(d.ctx, generations), "lmcma_hip_run");
         lmcma_hip_opt_summary sm;
         d.hip(lmcma_hip_opt_get(d.ctx, &sm, d.xmean.data()), "lmcma_hip_opt_get");
         d.itr = sm.itr;
@@ -608,25 +612,27 @@ void LMCMA::evaluatePopulation()
         d.rowsFresh = false;
         return;
     }
-    if (d.sampleIdx != 0) throw std::runtime_error("evaluatePopulation in the middle of an ask/tell generation");
-    // device: score, rank, recombine; host: the fp64 state transition
-    d.hip(lmcma_hip_evaluate(d.ctx), "lmcma_hip_evaluate");
-    std::vector<float> sortedF(d.lambda);
-    std::vector<int32_t> perm(d.lambda);
-    d.hip(lmcma_hip_select(d.ctx, sortedF.data(), perm.data()), "lmcma_hip_select");
-    d.xold = d.xmean;
-    d.hip(lmcma_hip_recombine(d.ctx, d.weights.data(), d.xmean.data()), "lmcma_hip_recombine");
-    std::vector<double> sorted(sortedF.begin(), sortedF.end());
-    // bookkeeping of lambda feedback calls (L/:190-198); the smallest cost decides BestF
-    for (int i = 0; i < d.lambda; ++i) d.lastCosts[perm[i]] = sorted[i];
-    const bool firstEver = counteval == 0;
-    counteval += d.lambda;
-    if (sorted[0] < BestF || firstEver) {
-        BestF = sorted[0];
-        if (d.verbose) std::cout << "Functions evaluation #" << counteval << ", value: " << BestF << std::endl;
+    for (int g = 0; g < generations; ++g) {
+        if (d.sampleIdx != 0) throw std::runtime_error("evaluatePopulation in the middle of an ask/tell generation");
+        // device: score, rank, recombine; host: the fp64 state transition
+        d.hip(lmcma_hip_evaluate(d.ctx), "lmcma_hip_evaluate");
+        std::vector<float> sortedF(d.lambda);
+        std::vector<int32_t> perm(d.lambda);
+        d.hip(lmcma_hip_select(d.ctx, sortedF.data(), perm.data()), "lmcma_hip_select");
+        d.xold = d.xmean;
+        d.hip(lmcma_hip_recombine(d.ctx, d.weights.data(), d.xmean.data()), "lmcma_hip_recombine");
+        std::vector<double> sorted(sortedF.begin(), sortedF.end());
+        // bookkeeping of lambda feedback calls (L/:190-198); the smallest cost decides BestF
+        for (int i = 0; i < d.lambda; ++i) d.lastCosts[perm[i]] = sorted[i];
+        const bool firstEver = counteval == 0;
+        counteval += d.lambda;
+        if (sorted[0] < BestF || firstEver) {
+            BestF = sorted[0];
+            if (d.verbose) std::cout << "Functions evaluation #" << counteval << ", value: " << BestF << std::endl;
+        }
+        advanceState(d, sorted);
+        sample();
     }
-    advanceState(d, sorted);
-    sample();
 }
 
 bool LMCMA::isBehaviorLearningDone() { return impl->sigma < 1e-20; }  // L/:426-429
