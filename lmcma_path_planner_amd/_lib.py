@@ -5,7 +5,9 @@ module raises if the shared object has not been built (``make -C
 lmcma_path_planner_amd/csrc`` or ``__graft_entry__.build()``).
 """
 import ctypes
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LMCMA_HIP_LIB", os.path.join(_HERE, "lib", "liblmcma_hip.so"))
@@ -162,6 +164,15 @@ def load():
         raise ImportError(
             "liblmcma_hip.so is not built (%s): run `make -C lmcma_path_planner_amd/csrc` "
             "or __graft_entry__.build(); there is no CPU fallback" % LIB_PATH)
+    # The PyTorch ROCm wheel ships its own copies of the HIP and HSA runtimes under other
+    # library names.  Loaded after this library's runtime they start a second runtime in the
+    # process, which finds no GPU ("No HIP GPUs are available"); loaded first, their symbols are
+    # global and this library's runtime binds to them, so both see the same device.  A process
+    # that will use torch next to this library (torch views of the library's buffers, RCCL
+    # through torch.distributed) therefore needs torch loaded first.
+    if os.environ.get("LMCMA_HIP_NO_TORCH_PRELOAD") is None and "torch" not in sys.modules:
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header and library disagree

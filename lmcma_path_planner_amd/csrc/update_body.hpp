@@ -440,21 +440,16 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, 
     // still sees exactly the reference's sequence of operations.  Vectors before imin
     // keep last generation's value (L/:375 starts at imin).
     //
-    // The squared norm of every vector is carried along instead of being summed again
-    // after the last transform: |K a - d v|^2 = K^2 |a|^2 - 2 K d (v.a) + d^2 |v|^2, all of
-    // whose terms are already in registers; so a step needs one cross-lane sum only.
-    if (rebuild) {
-        aa = 0.0;
+    // The squared norm of a vector is summed when the vector is final, by its owner, just
+    // before it is published.  (Carrying it through the transforms as |K a - d v|^2 =
+    // K^2 |a|^2 - 2 K d (v.a) + d^2 |v|^2 saves that sum but cancels: with 32 correlated
+    // paths the vectors drifted to 2e-9 of the fp64 recurrence, measured.)
+    if (newest) {
 #pragma unroll
         for (int e = 0; e < EMAX; ++e) {
-            const int n = e * 16 + lane;
-            if (newest) {
-                av[e] = s_pc[n];
-                pcq[e] = av[e];
-            }
-            aa += av[e] * av[e];
+            av[e] = s_pc[e * 16 + lane];
+            pcq[e] = av[e];
         }
-        aa = row16_sum(aa);
     }
     if (!KEEP_PC) {
         // the paths are read again at the end; keep the registers for the loop
@@ -469,11 +464,16 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, 
             // squared norm; vectors before imin were published above, once
             if (pos == i) {
                 double *dst = V_LDS ? s_v + (size_t)i * NP : a.v_arr + (size_t)slot * N;
+                double q0 = 0.0, q1 = 0.0;
 #pragma unroll
-                for (int e = 0; e < EMAX; ++e) {
-                    const int n = e * 16 + lane;
-                    if (V_LDS || n < N) dst[n] = av[e];
+                for (int e = 0; e < EMAX; e += 2) {
+                    const int n0 = e * 16 + lane, n1 = (e + 1) * 16 + lane;
+                    if (V_LDS || n0 < N) dst[n0] = av[e];
+                    if (V_LDS || n1 < N) dst[n1] = av[e + 1];
+                    q0 += av[e] * av[e];
+                    q1 += av[e + 1] * av[e + 1];
                 }
+                aa = row16_sum(q0 + q1);
                 if (lane == 0) s_nv[i] = aa;
             }
             // The next publication writes row i+1 and another norm word, so one barrier per
@@ -501,7 +501,6 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, 
             const double d = lji * p;
 #pragma unroll
             for (int e = 0; e < EMAX; ++e) av[e] = K * av[e] - d * vv[e];
-            aa = K * K * aa - 2.0 * K * d * p + d * d * nvi;
         }
     }
     LMCMA_STAMP(4);
@@ -702,8 +701,15 @@ __device__ __forceinline__ void update_pre_body(const UpdateArgs &a, double *s_d
         const bool fresh = i >= imin;  // same for every thread
         if (fresh) {
             if (pos == i && rebuild) {
+                double q0 = 0.0, q1 = 0.0;
 #pragma unroll
-                for (int e = 0; e < EMAX; ++e) s_v[(size_t)i * NP + e * 16 + lane] = av[e];
+                for (int e = 0; e < EMAX; e += 2) {
+                    s_v[(size_t)i * NP + e * 16 + lane] = av[e];
+                    s_v[(size_t)i * NP + (e + 1) * 16 + lane] = av[e + 1];
+                    q0 += av[e] * av[e];
+                    q1 += av[e + 1] * av[e + 1];
+                }
+                aa = row16_sum(q0 + q1);  // summed anew, not carried through the transforms (see update_body)
                 if (lane == 0) s_nv[i] = aa;
             }
             __syncthreads();
@@ -725,11 +731,16 @@ __device__ __forceinline__ void update_pre_body(const UpdateArgs &a, double *s_d
             const double d = lji * p;
 #pragma unroll
             for (int e = 0; e < EMAX; ++e) av[e] = K * av[e] - d * vv[e];
-            aa = K * K * aa - 2.0 * K * d * p + d * d * nvi;
         }
     }
     if (rebuild) {
-        // L/:386-389
+        // L/:386-389; the last vector rebuilt here (position isz - 2) was not published above
+        if (pos >= isz - 2) {
+            double q = 0.0;
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) q += av[e] * av[e];
+            aa = row16_sum(q);
+        }
         if (lane == 0) {
             a.nj[slot] = (sq / aa) * (sqrt(1 + ratio * aa) - 1);
             a.lj[slot] = lj_of(aa, sq, ratio);
