@@ -170,6 +170,23 @@ int lmcma_hip_get_terms(lmcma_hip_ctx *ctx, int first_local, int count, double *
 int lmcma_hip_score_rows(lmcma_hip_ctx *ctx, const float *rows, int count,
                          float *cost_out, float *terms_out);
 
+/* The ranking of lmcma_hip_select for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart
+ * in the reference.  All pointers are device memory of the calling thread's current device;
+ * `stream` (a hipStream_t, NULL = the null stream) belongs to that device.  Ascending order,
+ * equal costs in candidate order, NaN as +inf, exactly like lmcma_hip_select:
+ * sorted_cost_dev[lambda], perm_dev[lambda].  The kernels are queued on the stream; nothing
+ * is synchronised, and neither hipMalloc/hipFree nor any allocating routine is called.
+ * The sorted key tiles live in a fixed 1 MiB array of the library's code object on each GPU
+ * (held until the process ends), hence lambda <= LMCMA_HIP_RANK_NOALLOC_MAX_LAMBDA (larger:
+ * LMCMA_HIP_ERR_UNSUPPORTED).  Every call on a GPU shares that GPU's array: calls that overlap
+ * on one GPU (different streams, or threads) race; calls on one stream are safe back to
+ * back.  The array's address is looked up on a device's first lmcma_hip_create or first call
+ * here, whichever comes first: make that one outside a stream capture.               */
+#define LMCMA_HIP_RANK_NOALLOC_MAX_LAMBDA 131072
+int lmcma_hip_rank_noalloc(const float *cost_dev, int lambda, float *sorted_cost_dev,
+                           int32_t *perm_dev, void *stream);
+
 /* ---- device-resident optimiser: L/lmcma.cpp:313-424 without leaving the GPU -- */
 
 /* CMABase::init + LMCMA::init (L/lmcma.cpp:130-170, 262-296): xmean0[N] (the

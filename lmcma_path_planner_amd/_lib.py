@@ -90,6 +90,7 @@ SIGNATURES = {
     "lmcma_hip_evaluate": (_i, [_vp]),
     "lmcma_hip_set_costs": (_i, [_vp, _i, _i, c_double_p]),
     "lmcma_hip_select": (_i, [_vp, c_float_p, c_int32_p]),
+    "lmcma_hip_rank_noalloc": (_i, [_vp, _i, _vp, _vp, _vp]),
     "lmcma_hip_recombine": (_i, [_vp, c_double_p, c_double_p]),
     "lmcma_hip_get_rows": (_i, [_vp, _i, _i, c_double_p]),
     "lmcma_hip_get_costs": (_i, [_vp, _i, _i, c_double_p]),

@@ -23,6 +23,16 @@ int fail(int code, const std::string &msg)
     return code;
 }
 
+}  // namespace
+
+namespace lmcma {
+// for entry points defined beside their kernels
+int set_last_error(int code, const char *msg) { return fail(code, msg); }
+hipError_t rank_scratch_current_device(uint64_t **out);  // k_select.hip
+}  // namespace lmcma
+
+namespace {
+
 #define HIP_TRY(expr)                                                                        \
     do {                                                                                     \
         hipError_t _e = (expr);                                                              \
@@ -499,6 +509,12 @@ int lmcma_hip_create(const lmcma_hip_config *cfg, lmcma_hip_ctx **out)
     if (cfg->device < 0 || cfg->device >= ndev) return fail(LMCMA_HIP_ERR_ARG, "device ordinal out of range");
     HIP_TRY(hipSetDevice(cfg->device));
 
+    {
+        // set-up of lmcma_hip_rank_noalloc on this device, so that its first call need not be the one
+        // that looks the scratch array up
+        uint64_t *unused = nullptr;
+        HIP_TRY(rank_scratch_current_device(&unused));
+    }
     lmcma_hip_ctx *c = new lmcma_hip_ctx();
     c->cfg = *cfg;
     c->N = cfg->n_params;

@@ -19,6 +19,8 @@
 // tile: that sum is its global rank, and it scatters itself there.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "device_funcs.hpp"
 
 namespace lmcma {
@@ -223,3 +225,65 @@ hipError_t launch_select_sort(hipStream_t s, const SelectArgs &a)
 }
 
 }  // namespace lmcma
+
+// ---- ranking for callers that cannot allocate -------------------------------------------
+// The sorted key tiles of the sorting path, for populations up to
+// LMCMA_HIP_RANK_NOALLOC_MAX_LAMBDA, in a fixed array of the code object instead of a
+// context's workspace: 1 MiB per GPU the library runs on, held until the process ends.
+static_assert(LMCMA_HIP_RANK_NOALLOC_MAX_LAMBDA % lmcma::kSortTile == 0, "whole tiles");
+static __device__ __align__(256) uint64_t g_rank_scratch[LMCMA_HIP_RANK_NOALLOC_MAX_LAMBDA];
+
+namespace lmcma {
+
+// Device address of g_rank_scratch on the calling thread's current device (every GPU holds
+// its own copy of the array at its own address), looked up once per device.  Host code uses
+// this pointer, never the array's name, wherever it needs the array's memory.
+hipError_t rank_scratch_current_device(uint64_t **out)
+{
+    constexpr int kMaxDevices = 64;
+    static std::mutex mu;
+    static uint64_t *ptrs[kMaxDevices] = {};
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptrs[dev]) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_rank_scratch));
+        if (e != hipSuccess) return e;
+        ptrs[dev] = static_cast<uint64_t *>(p);
+    }
+    *out = ptrs[dev];
+    return hipSuccess;
+}
+
+int set_last_error(int code, const char *msg);  // capi.hip
+
+}  // namespace lmcma
+
+extern "C" int lmcma_hip_rank_noalloc(const float *cost_dev, int lambda, float *sorted_cost_dev, int32_t *perm_dev,
+                                      void *stream)
+{
+    using namespace lmcma;
+    if (!cost_dev || !sorted_cost_dev || !perm_dev) return set_last_error(LMCMA_HIP_ERR_ARG, "rank_noalloc: null buffer");
+    if (lambda < 1) return set_last_error(LMCMA_HIP_ERR_ARG, "rank_noalloc: lambda must be positive");
+    if (lambda > LMCMA_HIP_RANK_NOALLOC_MAX_LAMBDA)
+        return set_last_error(LMCMA_HIP_ERR_UNSUPPORTED,
+                              "rank_noalloc: at most 131072 costs (LMCMA_HIP_RANK_NOALLOC_MAX_LAMBDA); larger "
+                              "populations go through a context (lmcma_hip_select)");
+    uint64_t *scratch = nullptr;
+    if (rank_scratch_current_device(&scratch) != hipSuccess)
+        return set_last_error(LMCMA_HIP_ERR_RUNTIME, "rank_noalloc: hipGetSymbolAddress failed");
+    // every key of the tiles in use is written (padding included) before the merge reads it:
+    // nothing of the last call's contents is read, nothing has to start at zero
+    SelectArgs a{};
+    a.cost_all = cost_dev;
+    a.lambda = lambda;
+    a.keys_ws = scratch;
+    a.sorted_cost = sorted_cost_dev;
+    a.perm = perm_dev;
+    if (launch_select_sort(static_cast<hipStream_t>(stream), a) != hipSuccess)
+        return set_last_error(LMCMA_HIP_ERR_RUNTIME, "rank_noalloc: kernel launch failed");
+    return LMCMA_HIP_OK;
+}
