@@ -16,10 +16,12 @@ instead of one that has already collapsed (sigma < 1e-20 is the reference's stop
 condition, lmcma.cpp:426-429, reached after a few hundred generations here).
 
 Rank 0 prints one JSON line; besides the throughput it carries
-  roofline      the dominant kernel's algorithmic bytes per launch over its
-                HIP-event launch duration, against the 8 TB/s HBM3E peak
-  cpu_baseline  the CPU oracle (a port of the reference algorithm, fp64, one
-                thread) on a bounded sample of the same workload, N = 1 only
+  roofline      one generation's algorithmic bytes (bytes per candidate-trajectory x
+                candidates per GPU) over its device time (HIP events on the library's
+                stream around the timed steps), against the 8 TB/s HBM3E peak
+  cpu_baseline  the CPU oracle (a port of the reference algorithm, fp64) on a bounded
+                sample of the same workload, candidates spread over the box's host
+                threads; cpu_baseline_1thread: the same on one thread.  N = 1 only
 """
 import argparse
 import json
@@ -47,33 +49,53 @@ def algorithmic_bytes_per_launch(kernel, prob, lam_local, lam_total):
         return lam_local * (4 * N + 4) + prob.grid_bytes()
     if kernel == "generate":    # fused: write the rows, read V, B and the grid once, write one cost
         return lam_local * (4 * N + 4) + 8 * m * N + prob.grid_bytes()
-    if kernel == "select":      # read every cost; write sorted costs and ranks
-        return lam_total * (4 + 8)
-    if kernel == "recombine":   # read the local half of the mu = lambda/2 elite rows
-        return lam_local * 2 * N + (lam_total // 2) * 12
-    if kernel == "update":      # direction store in and out, previous/current sorted costs
-        return 8 * (4 * m * N) + 8 * lam_total
+    if kernel == "select":      # read every cost and last generation's sorted list; write sorted costs and
+        # ranks; the ranking launch also reads the elite rows it recombines (half of the local rows on
+        # average, mu = lambda / 2) and writes one fp64 partial row per 32 candidates
+        return lam_total * (4 + 4 + 8) + lam_local * 2 * N + (lam_local // 32) * 8 * N
+    if kernel == "recombine":   # row sums: the partial rows in, one row out
+        return (lam_local // 32) * 8 * N + 8 * N
+    if kernel == "update":      # direction store in and out, the partial rows, the float images out
+        return 8 * (4 * m * N) + min(lam_local // 32, 192) * 8 * N + 8 * m * N
     raise KeyError(kernel)
 
 
-def cpu_baseline(prob, budget_s=12.0):
-    """The oracle's generation loop (Philox z, fp64 sample/update, fp64 cost on
-    fp32-rounded rows) on the host, single thread, for about budget_s seconds."""
+def cpu_baseline(prob, threads, budget_s):
+    """The oracle's generation loop (the reference's ask/tell loop in C: Philox z, fp64
+    sample/update, fp64 cost of the float-rounded rows) on `threads` host threads for about
+    budget_s seconds.  Candidates are spread over the threads for sampling and scoring; the
+    update stays serial as in the reference."""
     from oracle import pyoracle
+    pyoracle.set_threads(threads)
     co = pyoracle.CostOracle(prob.dims, prob.W, prob.cells, prob.start, prob.goal)
     o = pyoracle.OracleLMCMA(prob.N, prob.lam, prob.m, initial=prob.x0, lo=prob.lo, hi=prob.hi,
                              sigma=prob.sigma0, seed=42, z_source=pyoracle.Z_PHILOX)
-    gens = 0
+    o.run_trajectory(co, 1)     # thread start-up, page faults
+    gens, chunk = 0, 2
     t0 = time.perf_counter()
     while True:
-        c, _ = co.cost_rows_f32(o.arx.astype(np.float32))
-        o.tell_all(c)
-        gens += 1
+        o.run_trajectory(co, chunk)
+        gens += chunk
         el = time.perf_counter() - t0
-        if el >= budget_s or gens >= 2000:
+        if el >= budget_s or gens >= 4000:
             break
-    return {"value": prob.lam * gens / el, "unit": "candidate-trajectories/s", "cores": 1, "kind": "port",
-            "sample": "%d generations of lambda=%d (%.1f s) of the same workload, fp64, one thread" % (gens, prob.lam, el)}
+        chunk = max(2, min(64, int(chunk * budget_s / max(el, 1e-3) / 8)))
+    pyoracle.set_threads(1)
+    return {"value": prob.lam * gens / el, "unit": "candidate-trajectories/s", "cores": threads, "kind": "port",
+            "sample": "%d generations of lambda=%d (%.1f s) of the same workload, fp64, %d host thread%s"
+                      % (gens, prob.lam, el, threads, "" if threads == 1 else "s over the candidates")}
+
+
+def host_threads():
+    """Host threads of this job's CPU share: OMP_NUM_THREADS when the box sets it, else the
+    affinity mask, at most 16."""
+    try:
+        n = int(os.environ.get("OMP_NUM_THREADS", "0"))
+    except ValueError:
+        n = 0
+    if n < 1:
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n, 16))
 
 
 def main():
@@ -154,39 +176,45 @@ def main():
         ctx.synchronize()
         torch.cuda.synchronize()
 
+    # Outside every timed region, whatever --warmup is: the library records its HIP graphs on the
+    # first run call (one eager generation, then the captures), modules load, LDS limits are raised.
+    run_steps(12)
+    fence()
     run_steps(args.warmup)
     fence()
     t0 = time.perf_counter()
+    ctx.stream_mark(0)
     run_steps(args.steps)
+    ctx.stream_mark(1)
     fence()
     elapsed = time.perf_counter() - t0
+    device_ms = ctx.stream_elapsed()        # HIP events on the library's stream around the same K steps
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel launch durations with HIP events on the library's stream, same number of steps
+    # Per-kernel launch durations: a second, eager pass with an event bracket around every launch.
+    # A bracket reads more than the kernel inside it.  The kernels of a generation run back to back
+    # on one stream, so their durations add up to the generation's device time, which the events
+    # around the replayed steps above give (device_ms, not the wall clock): the share of a bracket
+    # that is not kernel is (sum of the brackets per generation - that time) / brackets per generation.
+    # The rocprofv3 averages under profiles/ are the reference for these durations.
+    timed_steps = min(args.steps, 400)
     ctx.timing_enable(True)
-    if world == 1:
-        run_steps(args.steps)
-    else:
-        run_steps(min(args.steps, 200))
+    ctx.stream_mark(0)
+    run_steps(timed_steps)
+    ctx.stream_mark(1)
     fence()
+    eager_ms = ctx.stream_elapsed()
     timing = ctx.timing_get()
     ctx.timing_enable(False)
-    # An event bracket also reads time between the two records that is not the kernel (a few
-    # microseconds on this stack).  On one GPU the kernels of a generation run back to back
-    # on one stream, so their durations add up to the measured time per generation: the
-    # share of a bracket that is not kernel is chosen to make them do so.  (An empty bracket
-    # reads more than that share, a bracket around an empty kernel less; both are printed.)
     empty_bracket_us = ctx.timing_event_overhead(1024) * 1e3
-    timed_steps = args.steps if world == 1 else min(args.steps, 200)
-    brackets_per_step = sum(n for (_, n) in timing.values()) / timed_steps
-    bracket_us_per_step = sum(ms for (ms, _) in timing.values()) * 1e3 / timed_steps
-    if world == 1:
-        event_overhead_us = max((bracket_us_per_step - elapsed / args.steps * 1e6) / brackets_per_step, 0.0)
-    else:
-        event_overhead_us = 0.0   # collectives sit between the kernels: the brackets are reported as read
+    brackets = sum(n for (_, n) in timing.values())
+    bracket_sum_us = sum(ms for (ms, _) in timing.values()) * 1e3
+    gen_device_us = device_ms * 1e3 / args.steps
+    event_overhead_us = (max((bracket_sum_us / timed_steps - gen_device_us) / max(brackets / timed_steps, 1), 0.0)
+                         if world == 1 else 0.0)   # collectives sit between a shard's kernels: brackets as read
     st = ctx.opt_get()
 
     if rank == 0:
@@ -198,11 +226,19 @@ def main():
                 per_kernel[name] = {"avg_us": avg_s * 1e6, "bracket_us": ms * 1e3 / n, "launches": n, "bytes": b,
                                     "GBps": b / avg_s / 1e9}
         dominant = max(per_kernel, key=lambda k: per_kernel[k]["avg_us"] * per_kernel[k]["launches"])
+        # One generation = the chain of launches the library replays from its graph; its algorithmic
+        # bytes are bytes-per-candidate x the candidates this GPU owns, its duration the device time of
+        # the timed region / K (events on the library's stream).  That chain is what the roofline
+        # fraction is quoted for: no single kernel of it moves the generation's bytes.
+        b_cand = prob.algorithmic_bytes_per_candidate(lam_local)
+        gen_bytes = b_cand * lam_local
+        gen_us = device_ms * 1e3 / args.steps
+        achieved = gen_bytes / (gen_us * 1e-6) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_cfg%d.json" % args.config)
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(dominant)
-        achieved = per_kernel[dominant]["GBps"]
+            tj = json.load(open(tpath))
+            traffic = tj.get("generation")
         out = {
             "metric": "candidate-trajectories/sec (lambda x gens/s), 512^2 grid, 64-waypoint",
             "value": lam_total * args.steps / elapsed,
@@ -221,25 +257,21 @@ def main():
                        "lambda_total": lam_total, "m": prob.m, "z_source": "philox4x32-10",
                        "update": "on device, fp64", "episode_generations": EPISODE, "exchange": "all-gather of sorted local costs + all-gather of elite partial sums (N+2 doubles per rank)"
                        if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_launch": per_kernel[dominant]["bytes"],
-                         "avg_launch_us": per_kernel[dominant]["avg_us"],
-                         "event_bracket_us": per_kernel[dominant]["bracket_us"],
-                         # the whole generation against the same peak: algorithmic bytes per
-                         # candidate-trajectory x candidates per second (all ranks)
-                         "generation_achieved": lam_total * args.steps / elapsed *
-                         prob.algorithmic_bytes_per_candidate(lam_local) / 1e9,
-                         "generation_frac": lam_total * args.steps / elapsed *
-                         prob.algorithmic_bytes_per_candidate(lam_local) / 1e9 / (HBM_PEAK_GBS * world),
-                         "bracket_overhead_us": event_overhead_us,
-                         "empty_bracket_us": empty_bracket_us},
+            "roofline": {"bound": "hbm", "kernel": "one generation: " + " + ".join(k for k in per_kernel),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic,
+                         "bytes_per_launch": gen_bytes, "bytes_per_candidate": b_cand,
+                         "avg_launch_us": gen_us,
+                         "longest_kernel": dominant},
             "kernels": per_kernel,
-            "generation_bytes_per_candidate": prob.algorithmic_bytes_per_candidate(lam_local),
+            "event_brackets": {"overhead_us": event_overhead_us, "empty_bracket_us": empty_bracket_us,
+                               "eager_pass_us_per_step": eager_ms * 1e3 / timed_steps},
             "final": {"generations": st["itr"], "best_f": st["best_f"], "sigma": st["sigma"]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(prob)
+            cores = host_threads()
+            out["cpu_baseline"] = cpu_baseline(prob, cores, 12.0)
+            out["cpu_baseline_1thread"] = cpu_baseline(prob, 1, 8.0)
         print(json.dumps(out))
     ctx.close()
     if world > 1:

@@ -202,7 +202,12 @@ int lmcma_hip_opt_reset(lmcma_hip_ctx *ctx);
 /* n whole generations: sample -> evaluate -> select -> recombine -> update
  * (the body of CMABase::setEvaluationFeedback's every-lambda-th call,
  * L/lmcma.cpp:199-204, plus the caller's cost loop), queued on the stream.
- * Needs lambda_local == lambda_total, z_source PHILOX, cost_source TRAJECTORY. */
+ * Needs lambda_local == lambda_total, z_source PHILOX, cost_source TRAJECTORY.
+ * The reference's caller stops when isBehaviorLearningDone() (sigma < 1e-20,
+ * L/lmcma.cpp:426-429); here the update kernels evaluate that rule: once it has
+ * fired the state is left as it is, so generations queued beyond it change
+ * nothing and lmcma_hip_opt_summary.itr is the generation that reached it.
+ * The first call on a context also records the HIP graphs later calls replay. */
 int lmcma_hip_run(lmcma_hip_ctx *ctx, int n_generations);
 
 /* The same generation in pieces, for a population sharded over contexts:
@@ -232,6 +237,9 @@ typedef struct {
     double best_f;        /* L/lmcma.hpp:65                                      */
     double sigma;
     double s;             /* success-rule accumulator                            */
+    int32_t done;         /* LMCMA::isBehaviorLearningDone, L/lmcma.cpp:426-429:  */
+                          /* sigma < 1e-20 was reached in generation itr          */
+    int32_t reserved;
 } lmcma_hip_opt_summary;
 
 /* synchronises the stream */
@@ -262,6 +270,11 @@ enum {
 int lmcma_hip_buffer(lmcma_hip_ctx *ctx, int which, void **device_ptr, size_t *bytes);
 int lmcma_hip_row_stride(lmcma_hip_ctx *ctx); /* ld: floats between rows */
 int lmcma_hip_synchronize(lmcma_hip_ctx *ctx);
+
+/* Device time of a stretch of work on the context's stream: mark(0) before it is queued,
+ * mark(1) after; stream_elapsed waits for mark 1 and returns the milliseconds between.   */
+int lmcma_hip_stream_mark(lmcma_hip_ctx *ctx, int which);
+int lmcma_hip_stream_elapsed(lmcma_hip_ctx *ctx, double *ms);
 
 /* kernel timing with HIP events on the context's stream: records around every
  * kernel class while enabled; totals in milliseconds and launch counts.       */

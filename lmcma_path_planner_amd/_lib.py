@@ -55,6 +55,8 @@ class OptSummary(ctypes.Structure):
         ("best_f", ctypes.c_double),
         ("sigma", ctypes.c_double),
         ("s", ctypes.c_double),
+        ("done", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 
@@ -108,6 +110,8 @@ SIGNATURES = {
     "lmcma_hip_buffer": (_i, [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_size_t)]),
     "lmcma_hip_row_stride": (_i, [_vp]),
     "lmcma_hip_synchronize": (_i, [_vp]),
+    "lmcma_hip_stream_mark": (_i, [_vp, _i]),
+    "lmcma_hip_stream_elapsed": (_i, [_vp, c_double_p]),
     "lmcma_hip_timing_enable": (_i, [_vp, _i]),
     "lmcma_hip_timing_get": (_i, [_vp, c_double_p, c_int64_p]),
     "lmcma_hip_timing_event_overhead": (_i, [_vp, _i, c_double_p]),

@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -29,6 +31,24 @@ namespace lmcma {
 // for entry points defined beside their kernels
 int set_last_error(int code, const char *msg) { return fail(code, msg); }
 hipError_t rank_scratch_current_device(uint64_t **out);  // k_select.hip
+
+hipError_t ensure_dynamic_lds(const void *kernel, size_t lds)
+{
+    if (lds <= 48 * 1024) return hipSuccess;  // within every kernel's default limit
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> configured;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = configured[{dev, kernel}];
+    if (lds > have) {
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        have = lds;
+    }
+    return hipSuccess;
+}
 }  // namespace lmcma
 
 namespace {
@@ -55,7 +75,8 @@ __global__ void k_set_sample_scalars(SampleScalars *sc, float sigma, float mk, i
 
 // back to the state lmcma_hip_opt_init left: mean, step size, empty direction store
 __global__ void k_opt_reset(OptScalars *opt, SampleScalars *sc, const double *xmean0, double sigma0,
-                            double *xmean, float *xmean_f, double *pc, int N, int ld)
+                            double *xmean, float *xmean_f, double *pc, int N, int ld,
+                            unsigned long long *psr_accum)
 {
     for (int n = threadIdx.x; n < ld; n += blockDim.x) {
         const double x = n < N ? xmean0[n] : 0.0;
@@ -72,6 +93,8 @@ __global__ void k_opt_reset(OptScalars *opt, SampleScalars *sc, const double *xm
         opt->counteval = 0;
         opt->itr = 0;
         opt->iterator_sz = 0;
+        opt->done = 0;
+        *psr_accum = 0ull;  // (an update that the stop rule froze has not cleared it)
         sc->sigma = (float)sigma0;
         sc->mk = 1.0f;
         sc->k = 0;
@@ -85,7 +108,9 @@ struct EventPair {
 };
 
 constexpr int kMaxPartials = 64;
-constexpr int kGensPerGraph = 8;
+// generations per recorded graph: a long one for the bulk of a run, a short one for its tail
+// (both even: the two sorted-cost buffers alternate per generation)
+constexpr int kGensPerGraph[2] = {8, 2};
 
 }  // namespace
 
@@ -140,8 +165,9 @@ struct lmcma_hip_ctx {
     bool have_state = false, have_weights = false, opt_ready = false;
     bool sampled = false, costs_ready = false, selected = false;
 
-    hipGraphExec_t graph_exec = nullptr;
-    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipEvent_t mark[2] = {nullptr, nullptr};
 
     bool timing = false;
     std::vector<EventPair> ev_pool;
@@ -192,8 +218,10 @@ struct Arena {
 
 void drop_graph(lmcma_hip_ctx *c)
 {
-    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+    for (int q = 0; q < 2; ++q) {
+        if (c->graph_exec[q]) { (void)hipGraphExecDestroy(c->graph_exec[q]); c->graph_exec[q] = nullptr; }
+        if (c->graph[q]) { (void)hipGraphDestroy(c->graph[q]); c->graph[q] = nullptr; }
+    }
 }
 
 int fold_events(lmcma_hip_ctx *c)
@@ -601,6 +629,8 @@ int lmcma_hip_destroy(lmcma_hip_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graph(c);
     for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (hipEvent_t ev : c->mark)
+        if (ev) (void)hipEventDestroy(ev);
     void *bufs[] = {c->arena, c->zbuf, c->cov_L, c->scratch_rows, c->scratch_cost, c->scratch_terms, c->grid};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -881,6 +911,10 @@ int lmcma_hip_set_costs(lmcma_hip_ctx *c, int first, int count, const double *co
 int lmcma_hip_select(lmcma_hip_ctx *c, float *sorted_cost, int32_t *perm)
 {
     CTX_TRY(c);
+    // a context that holds the whole population knows whether it has this generation's costs (a
+    // shard's other costs arrive through LMCMA_BUF_COST_ALL, which the library cannot see)
+    if (c->nloc == c->lambda && !c->costs_ready)
+        return fail(LMCMA_HIP_ERR_STATE, "select: no costs yet (evaluate or set_costs must come first)");
     int rc = do_select(c, false, nullptr);
     if (rc != LMCMA_HIP_OK) return rc;
     if (sorted_cost)
@@ -1046,7 +1080,7 @@ int lmcma_hip_opt_reset(lmcma_hip_ctx *c)
     if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
     c->pre_done = false;
     hipLaunchKernelGGL(k_opt_reset, dim3(1), dim3(256), 0, c->stream, c->opt, c->sc, c->xmean0, c->sigma0,
-                       c->xmean, c->xmean_f, c->pc, c->N, c->ld);
+                       c->xmean, c->xmean_f, c->pc, c->N, c->ld, c->psr_accum);
     HIP_TRY(hipGetLastError());
     return LMCMA_HIP_OK;
 }
@@ -1062,38 +1096,40 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
     if (n_generations < 0) return fail(LMCMA_HIP_ERR_ARG, "negative generation count");
     int left = n_generations;
     const bool use_graph = !c->timing && getenv("LMCMA_HIP_NO_GRAPH") == nullptr;
-    while (use_graph && left >= kGensPerGraph) {
-        if (!c->graph_exec) {
-            if (!c->warmed) {
-                // one eager generation first: module load and LDS attribute calls stay out of the capture
-                int rc = one_generation(c);
-                if (rc != LMCMA_HIP_OK) return rc;
-                --left;
-                c->warmed = true;
-                continue;
-            }
-            static_assert(kGensPerGraph % 2 == 0, "the sorted-cost buffers alternate per generation");
-            c->graph_parity = c->parity;
-            HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            int crc = LMCMA_HIP_OK;
-            for (int g = 0; g < kGensPerGraph && crc == LMCMA_HIP_OK; ++g) crc = one_generation(c);
-            hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
-            if (crc != LMCMA_HIP_OK) { drop_graph(c); return crc; }
-            if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
-            e = hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0);
-            if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
-            // the capture only recorded the launches: none of the generations has run
-        }
-        if (c->parity != c->graph_parity) {
-            // the graph was recorded starting from the other sorted-cost buffer: step once eagerly
+    if (use_graph && left > 0 && !c->graph_exec[0]) {
+        // The graphs are recorded on the first call, whatever its length, so that no later call
+        // pays for it: one eager generation first (module load and LDS attribute calls stay out
+        // of the capture), then the launches of 8 and of 2 generations are recorded.  A capture
+        // records only: none of the recorded generations has run, and the host-side bookkeeping
+        // they went through (the buffer parity, pre_done) ends where it started.
+        if (!c->warmed) {
             int rc = one_generation(c);
             if (rc != LMCMA_HIP_OK) return rc;
             --left;
-            continue;
+            c->warmed = true;
         }
-        HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
-        left -= kGensPerGraph;
+        c->graph_parity = c->parity;
+        for (int q = 0; q < 2; ++q) {
+            static_assert(kGensPerGraph[0] % 2 == 0 && kGensPerGraph[1] % 2 == 0,
+                          "the sorted-cost buffers alternate per generation");
+            HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            int crc = LMCMA_HIP_OK;
+            for (int g = 0; g < kGensPerGraph[q] && crc == LMCMA_HIP_OK; ++g) crc = one_generation(c);
+            hipError_t e = hipStreamEndCapture(c->stream, &c->graph[q]);
+            if (crc != LMCMA_HIP_OK) { drop_graph(c); return crc; }
+            if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
+            e = hipGraphInstantiate(&c->graph_exec[q], c->graph[q], nullptr, nullptr, 0);
+            if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+        }
     }
+    if (use_graph && left > 0 && c->parity != c->graph_parity) {
+        // the graphs were recorded starting from the other sorted-cost buffer: step once eagerly
+        int rc = one_generation(c);
+        if (rc != LMCMA_HIP_OK) return rc;
+        --left;
+    }
+    for (int q = 0; use_graph && q < 2; ++q)
+        for (; left >= kGensPerGraph[q]; left -= kGensPerGraph[q]) HIP_TRY(hipGraphLaunch(c->graph_exec[q], c->stream));
     for (; left > 0; --left) {
         int rc = one_generation(c);
         if (rc != LMCMA_HIP_OK) return rc;
@@ -1197,6 +1233,8 @@ int lmcma_hip_opt_get(lmcma_hip_ctx *c, lmcma_hip_opt_summary *summary, double *
         summary->best_f = o.best_f;
         summary->sigma = o.sigma;
         summary->s = o.s;
+        summary->done = o.done;
+        summary->reserved = 0;
     }
     return LMCMA_HIP_OK;
 }
@@ -1243,6 +1281,27 @@ int lmcma_hip_synchronize(lmcma_hip_ctx *c)
 {
     CTX_TRY(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_stream_mark(lmcma_hip_ctx *c, int which)
+{
+    CTX_TRY(c);
+    if (which != 0 && which != 1) return fail(LMCMA_HIP_ERR_ARG, "stream_mark: which is 0 or 1");
+    if (!c->mark[which]) HIP_TRY(hipEventCreate(&c->mark[which]));
+    HIP_TRY(hipEventRecord(c->mark[which], c->stream));
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_stream_elapsed(lmcma_hip_ctx *c, double *ms)
+{
+    CTX_TRY(c);
+    if (!ms) return fail(LMCMA_HIP_ERR_ARG, "stream_elapsed: null argument");
+    if (!c->mark[0] || !c->mark[1]) return fail(LMCMA_HIP_ERR_STATE, "stream_elapsed: both marks must have been recorded");
+    HIP_TRY(hipEventSynchronize(c->mark[1]));
+    float f = 0.f;
+    HIP_TRY(hipEventElapsedTime(&f, c->mark[0], c->mark[1]));
+    *ms = (double)f;
     return LMCMA_HIP_OK;
 }
 

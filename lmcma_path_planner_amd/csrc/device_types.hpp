@@ -28,7 +28,9 @@ struct OptScalars {
     // constants derived once at init (L/lmcma.cpp:136-156, 266-272)
     double mueff, c1, cc, cs, val_target, K, M;
     int32_t imin_last;   // first recomputed vector of the last update (diagnostic)
-    int32_t pad;
+    // 1 once sigma < 1e-20 (LMCMA::isBehaviorLearningDone, L/lmcma.cpp:426-429): the update
+    // kernels then leave the state as it is, so itr stays at the generation that reached it
+    int32_t done;
 };
 
 struct CostParams {
@@ -68,6 +70,11 @@ struct GenParams {
     CostParams cost;          // cost.rows is not used: the rows come from LDS
     CovFactor cov;            // cov.L null: identity
 };
+
+// Raises a kernel's dynamic LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) when `lds`
+// exceeds what has been configured for it on the calling thread's current device; the sizes
+// are kept per (device, kernel) under a lock (capi.hip).
+hipError_t ensure_dynamic_lds(const void *kernel, size_t lds);
 
 // ---- launchers (each in the .hip file that defines its kernels) -------------
 hipError_t launch_generate(hipStream_t s, const GenParams &g, int dims, bool lds_grid);

@@ -35,6 +35,7 @@ int guarded(F &&f)
 
 struct lmcma_opt {
     std::vector<double> initial, lo, hi, cov;
+    int n = 0;               // entries of initial / lo / hi (cov: n * n): the only N init() may be given
     LMCMA *opt = nullptr;
     SepCMA *sep = nullptr;   // a handle holds one of the three optimisers
     CMAChol *chol = nullptr;
@@ -57,6 +58,7 @@ int lmcma_opt_create(const double *initial, const double *lo, const double *hi, 
     if (!out || n < 1) { g_err = "lmcma_opt_create: bad arguments"; return -1; }
     return guarded([&] {
         lmcma_opt *h = new lmcma_opt();
+        h->n = n;
         if (initial) h->initial.assign(initial, initial + n);
         if (lo) h->lo.assign(lo, lo + n);
         if (hi) h->hi.assign(hi, hi + n);
@@ -73,6 +75,7 @@ int lmcma_opt_create_sep(const double *initial, const double *lo, const double *
     if (!out || n < 1) { g_err = "lmcma_opt_create_sep: bad arguments"; return -1; }
     return guarded([&] {
         lmcma_opt *h = new lmcma_opt();
+        h->n = n;
         if (initial) h->initial.assign(initial, initial + n);
         if (lo) h->lo.assign(lo, lo + n);
         if (hi) h->hi.assign(hi, hi + n);
@@ -89,6 +92,7 @@ int lmcma_opt_create_chol(const double *initial, const double *lo, const double 
     if (!out || n < 1) { g_err = "lmcma_opt_create_chol: bad arguments"; return -1; }
     return guarded([&] {
         lmcma_opt *h = new lmcma_opt();
+        h->n = n;
         if (initial) h->initial.assign(initial, initial + n);
         if (lo) h->lo.assign(lo, lo + n);
         if (hi) h->hi.assign(hi, hi + n);
@@ -149,6 +153,8 @@ int lmcma_opt_set_problem(lmcma_opt *o, int dims, int waypoints, int nx, int ny,
 int lmcma_opt_init(lmcma_opt *o, int N)
 {
     if (!o) { g_err = "null handle"; return -1; }
+    // init reads N entries of the arrays the handle copied at creation
+    if (N != o->n) { g_err = "lmcma_opt_init: N differs from the n the handle was created with"; return -1; }
     return guarded([&] { o->base()->init(N); });
 }
 

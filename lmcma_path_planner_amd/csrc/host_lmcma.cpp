@@ -599,10 +599,17 @@ void LMCMA::step(int generations)
     if (!d.haveProblem) throw std::runtime_error("step needs setTrajectoryProblem");
     if (generations < 1) return;
     if (d.deviceUpdate) {
-        // all of them in one call: the library replays captured generations back to back
-        d.hip(lmcma_hip_run(d.ctx, generations), "lmcma_hip_run");
+        // the library replays captured generations back to back; the stop rule (L/:426-429) is
+        // evaluated on the device and freezes the state, and it is looked at here every 512
+        // generations so that a run that has stopped returns early
         lmcma_hip_opt_summary sm;
-        d.hip(lmcma_hip_opt_get(d.ctx, &sm, d.xmean.data()), "lmcma_hip_opt_get");
+        for (int left = generations; left > 0;) {
+            const int n = left < 512 ? left : 512;
+            d.hip(lmcma_hip_run(d.ctx, n), "lmcma_hip_run");
+            left -= n;
+            d.hip(lmcma_hip_opt_get(d.ctx, &sm, d.xmean.data()), "lmcma_hip_opt_get");
+            if (sm.done) break;
+        }
         d.itr = sm.itr;
         d.sigma = sm.sigma;
         d.s = sm.s;

@@ -96,12 +96,9 @@ hipError_t launch_gd(hipStream_t s, const CostParams &p, bool lds_grid)
         const int blocks = min(ntiles, 256);
         // raise the kernel's dynamic-LDS limit once per size (not a stream operation,
         // so it is kept out of the steady-state launch path and of graph captures)
-        static size_t configured = 0;
-        if (lds > configured) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cost<G, D, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        {
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_cost<G, D, true>), lds);
             if (e != hipSuccess) return e;
-            configured = lds;
         }
         hipLaunchKernelGGL((k_cost<G, D, true>), dim3(blocks), dim3(256), lds, s, p);
     } else {

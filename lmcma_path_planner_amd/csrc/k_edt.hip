@@ -167,12 +167,9 @@ hipError_t launch_axis(hipStream_t s, const uint32_t *in, uint32_t *out, int nx,
                        long outer_stride, int n_outer, const EdtOut &fin)
 {
     const size_t lds = (size_t)n * TX * sizeof(uint32_t);
-    static size_t configured = 48 * 1024;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edt_axis<TX, LAST>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_edt_axis<TX, LAST>), lds);
         if (e != hipSuccess) return e;
-        configured = lds;
     }
     const long tiles = (long)((nx + TX - 1) / TX) * n_outer;
     // about four workgroups per CU, each with at least one round of positions

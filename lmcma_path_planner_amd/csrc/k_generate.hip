@@ -287,12 +287,9 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
 template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV>
 hipError_t launch_t(hipStream_t s, const GenParams &g, size_t lds, int blocks)
 {
-    static size_t configured = 48 * 1024;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_generate<J, D, GRID_LDS, VB_LDS, COV>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_generate<J, D, GRID_LDS, VB_LDS, COV>), lds);
         if (e != hipSuccess) return e;
-        configured = lds;
     }
     hipLaunchKernelGGL((k_generate<J, D, GRID_LDS, VB_LDS, COV>), dim3(blocks), dim3(256), lds, s, g);
     return hipGetLastError();

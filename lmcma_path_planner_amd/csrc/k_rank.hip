@@ -513,12 +513,9 @@ hipError_t launch_rank_merge_t(hipStream_t s, const RankMergeArgs &r, int blocks
     const int keys = r.lambda < kMergeChunk ? r.lambda : kMergeChunk;
     const size_t lds = ((size_t)(((TB > r.N ? TB : r.N) + 1) & ~1) + CPB) * sizeof(double) + (size_t)CPB * sizeof(int) +
                        (size_t)(16 + keys) * sizeof(uint32_t);
-    static size_t configured = 48 * 1024;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rank_merge<TB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_rank_merge<TB>), lds);
         if (e != hipSuccess) return e;
-        configured = lds;
     }
     hipLaunchKernelGGL((k_rank_merge<TB>), dim3(blocks), dim3(TB), lds, s, r);
     return hipGetLastError();
@@ -527,12 +524,9 @@ hipError_t launch_rank_merge_t(hipStream_t s, const RankMergeArgs &r, int blocks
 template <int TB, int PRE_EMAX>
 hipError_t launch_rank_tp(hipStream_t s, const RankArgs &r, int blocks, size_t lds)
 {
-    static size_t configured = 48 * 1024;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rank<TB, PRE_EMAX>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_rank<TB, PRE_EMAX>), lds);
         if (e != hipSuccess) return e;
-        configured = lds;
     }
     hipLaunchKernelGGL((k_rank<TB, PRE_EMAX>), dim3(blocks + (PRE_EMAX > 0 ? 1 : 0)), dim3(TB), lds, s, r);
     return hipGetLastError();

@@ -210,12 +210,9 @@ template <int TB, int EMAX, bool V_LDS>
 static hipError_t launch_update_t(hipStream_t s, const UpdateArgs &a)
 {
     const size_t lds = update_lds_doubles(a.N, a.m, update_row_threads(TB), V_LDS) * sizeof(double);
-    static size_t configured = 48 * 1024;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_update<TB, EMAX, V_LDS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_update<TB, EMAX, V_LDS>), lds);
         if (e != hipSuccess) return e;
-        configured = lds;
     }
     hipLaunchKernelGGL((k_update<TB, EMAX, V_LDS>), dim3(1), dim3(update_block_threads(TB)), lds, s, a);
     return hipGetLastError();
@@ -225,12 +222,9 @@ template <int TB, int EMAX>
 static hipError_t launch_pre_t(hipStream_t s, const UpdateArgs &a)
 {
     const size_t lds = update_pre_lds_doubles(a.N, a.m) * sizeof(double);
-    static size_t configured = 48 * 1024;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_update_pre<TB, EMAX>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_update_pre<TB, EMAX>), lds);
         if (e != hipSuccess) return e;
-        configured = lds;
     }
     hipLaunchKernelGGL((k_update_pre<TB, EMAX>), dim3(1), dim3(TB), lds, s, a);
     return hipGetLastError();
@@ -240,12 +234,9 @@ template <int TB, int EMAX>
 static hipError_t launch_post_t(hipStream_t s, const UpdateArgs &a)
 {
     const size_t lds = update_post_lds_doubles(a.N, a.m, update_row_threads(TB)) * sizeof(double);
-    static size_t configured = 48 * 1024;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_update_post<TB, EMAX>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_update_post<TB, EMAX>), lds);
         if (e != hipSuccess) return e;
-        configured = lds;
     }
     hipLaunchKernelGGL((k_update_post<TB, EMAX>), dim3(1), dim3(update_block_threads(TB)), lds, s, a);
     return hipGetLastError();

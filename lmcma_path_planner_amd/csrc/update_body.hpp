@@ -232,6 +232,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, 
     const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
     const int N = a.N, m = a.m, lambda = a.lambda;
     OptScalars &o = *a.opt;
+    if (o.done) return;  // the stop rule has fired (L/:426-429): the state stays as it is
     const double sigma = o.sigma, cc = o.cc, c1 = o.c1, K = o.K, Mfac = o.M;
     const int itr = o.itr;
     const bool worker = tid < T;
@@ -555,6 +556,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, 
         o.itr = itr + 1;
         o.iterator_sz = isz;
         o.imin_last = imin;
+        o.done = new_sigma < 1e-20 ? 1 : 0;  // L/:426-429
         a.sc->sigma = (float)new_sigma;
         a.sc->mk = (float)mk;
         a.sc->k = isz;
@@ -640,6 +642,7 @@ __device__ __forceinline__ void update_pre_body(const UpdateArgs &a, double *s_d
     if (tid >= T) return;
     const int N = a.N, m = a.m;
     const OptScalars &o = *a.opt;
+    if (o.done) return;  // nothing is rebuilt once the stop rule has fired (see update_body)
     const double c1 = o.c1, K = o.K;
     const int itr = o.itr;
     const bool worker = true;
@@ -769,6 +772,7 @@ __device__ __forceinline__ void update_post_body(const UpdateArgs &a, double *s_
     const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
     const int N = a.N, m = a.m, lambda = a.lambda;
     OptScalars &o = *a.opt;
+    if (o.done) return;  // see update_body
     const double sigma = o.sigma, cc = o.cc, c1 = o.c1, K = o.K, Mfac = o.M;
     const int itr = o.itr;
     const bool worker = tid < T;
@@ -1001,6 +1005,7 @@ __device__ __forceinline__ void update_post_body(const UpdateArgs &a, double *s_
         o.itr = itr + 1;
         o.iterator_sz = isz;
         o.imin_last = imin;
+        o.done = new_sigma < 1e-20 ? 1 : 0;  // L/:426-429
         a.sc->sigma = (float)new_sigma;
         a.sc->mk = (float)mk;
         a.sc->k = isz;

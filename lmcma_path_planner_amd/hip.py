@@ -206,7 +206,7 @@ class HipContext:
         xm = np.empty(self.N, dtype=np.float64)
         check_hip(self.lib.lmcma_hip_opt_get(self._h, ctypes.byref(sm), _dp(xm)), "lmcma_hip_opt_get")
         return dict(itr=sm.itr, iterator_sz=sm.iterator_sz, counteval=sm.counteval, best_f=sm.best_f,
-                    sigma=sm.sigma, s=sm.s, xmean=xm)
+                    sigma=sm.sigma, s=sm.s, done=bool(sm.done), xmean=xm)
 
     def opt_vectors(self):
         N, m = self.N, self.m
@@ -232,6 +232,15 @@ class HipContext:
 
     def synchronize(self):
         check_hip(self.lib.lmcma_hip_synchronize(self._h), "lmcma_hip_synchronize")
+
+    def stream_mark(self, which):
+        check_hip(self.lib.lmcma_hip_stream_mark(self._h, int(which)), "lmcma_hip_stream_mark")
+
+    def stream_elapsed(self):
+        """Milliseconds of device time between stream_mark(0) and stream_mark(1)."""
+        ms = ctypes.c_double(0.0)
+        check_hip(self.lib.lmcma_hip_stream_elapsed(self._h, ctypes.byref(ms)), "lmcma_hip_stream_elapsed")
+        return ms.value
 
     def timing_enable(self, on=True):
         check_hip(self.lib.lmcma_hip_timing_enable(self._h, 1 if on else 0), "lmcma_hip_timing_enable")

@@ -384,19 +384,43 @@ static void inv_az(int N, double *Av, int iterator_sz, const int *iterator,
     }
 }
 
-static void sample_one(orc_lmcma *o, int i, const double *z)
+/* Host threads for the loops over candidates (the reference is single-threaded; candidates
+ * are independent given the state, so the per-candidate arithmetic and results do not depend
+ * on the thread count).  Used by the timed CPU baseline only; 1 = the reference's serial loop. */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int orc_get_threads(void) { return g_threads; }
+
+static void sample_one(orc_lmcma *o, int i, const double *z, double *Az)
 {
     /* L/lmcma.cpp:306-308 */
     int N = o->N;
-    compute_az(o, o->Az, z);
+    compute_az(o, Az, z);
     for (int k = 0; k < N; ++k)
-        o->arx[i * N + k] = o->xmean[k] + o->sigma * o->Az[k];
+        o->arx[i * N + k] = o->xmean[k] + o->sigma * Az[k];
 }
 
 void orc_lmcma_sample(orc_lmcma *o)
 {
     /* L/lmcma.cpp:301-311 with sampleStandardNormal :212-218 */
     int N = o->N;
+    if (o->z_source == ORC_Z_PHILOX && g_threads > 1) {
+        /* counter-based normals: candidate i's stream does not depend on the others */
+#pragma omp parallel num_threads(g_threads)
+        {
+            double *z = (double *)malloc(2 * (size_t)N * sizeof(double)), *Az = z + N;
+#pragma omp for schedule(static)
+            for (int i = 0; i < o->lambda; ++i) {
+                orc_philox_normals(o->philox_seed, (uint32_t)o->itr, (uint32_t)i, N, z);
+                if (o->L)
+                    orc_apply_cov_l(o->L, z, N);
+                sample_one(o, i, z, Az);
+            }
+            free(z);
+        }
+        apply_boundaries(o);
+        return;
+    }
     for (int i = 0; i < o->lambda; ++i) {
         if (o->z_source == ORC_Z_PHILOX) {
             orc_philox_normals(o->philox_seed, (uint32_t)o->itr, (uint32_t)i, N, o->z);
@@ -406,7 +430,7 @@ void orc_lmcma_sample(orc_lmcma *o)
         }
         if (o->L)
             orc_apply_cov_l(o->L, o->z, N);
-        sample_one(o, i, o->z);
+        sample_one(o, i, o->z, o->Az);
     }
     apply_boundaries(o);
 }
@@ -418,7 +442,7 @@ void orc_lmcma_sample_given(orc_lmcma *o, const double *Z)
         memcpy(o->z, Z + (size_t)i * N, (size_t)N * sizeof(double));
         if (o->L)
             orc_apply_cov_l(o->L, o->z, N);
-        sample_one(o, i, o->z);
+        sample_one(o, i, o->z, o->Az);
     }
     apply_boundaries(o);
 }
@@ -801,13 +825,42 @@ void orc_cost_rows_f32(const orc_problem *p, const float *rows, int count,
                        double *cost, double *terms)
 {
     int N = p->dims * p->waypoints;
-    double *row = (double *)malloc((size_t)N * sizeof(double));
-    for (int i = 0; i < count; ++i) {
-        for (int n = 0; n < N; ++n)
-            row[n] = (double)rows[(size_t)i * N + n];
-        cost[i] = orc_cost(p, row, terms ? terms + 3 * (size_t)i : NULL);
+#pragma omp parallel num_threads(g_threads) if (g_threads > 1)
+    {
+        double *row = (double *)malloc((size_t)N * sizeof(double));
+#pragma omp for schedule(static)
+        for (int i = 0; i < count; ++i) {
+            for (int n = 0; n < N; ++n)
+                row[n] = (double)rows[(size_t)i * N + n];
+            cost[i] = orc_cost(p, row, terms ? terms + 3 * (size_t)i : NULL);
+        }
+        free(row);
     }
-    free(row);
+}
+
+/* The whole generation loop on the host, for the timed CPU baseline: the ask/tell loop of
+ * L/example_lmcma.cpp:49-60 with the trajectory cost as the caller's function, the rows
+ * rounded to float first (the precision the device stores them in).  The scoring loop runs
+ * on orc_set_threads() threads, the sampling too when the normals are counter-based. */
+void orc_lmcma_run_trajectory(orc_lmcma *o, const orc_problem *p, int generations)
+{
+    int N = o->N, lambda = o->lambda;
+    double *cost = (double *)malloc((size_t)lambda * sizeof(double));
+    for (int g = 0; g < generations; ++g) {
+#pragma omp parallel num_threads(g_threads) if (g_threads > 1)
+        {
+            double *row = (double *)malloc((size_t)N * sizeof(double));
+#pragma omp for schedule(static)
+            for (int i = 0; i < lambda; ++i) {
+                for (int n = 0; n < N; ++n)
+                    row[n] = (double)(float)o->arx[(size_t)i * N + n];
+                cost[i] = orc_cost(p, row, NULL);
+            }
+            free(row);
+        }
+        orc_lmcma_tell_all(o, cost);
+    }
+    free(cost);
 }
 
 double orc_toy_cost(double x, double y)

@@ -128,6 +128,10 @@ typedef struct {
 
 /* terms[0..2] = J_len, J_grid, J_smooth (unweighted); returns the weighted total */
 double orc_cost(const orc_problem *p, const double *row, double *terms);
+void orc_lmcma_run_trajectory(orc_lmcma *o, const orc_problem *p, int generations);
+/* host threads for the loops over candidates (timed CPU baseline); default 1 */
+void orc_set_threads(int n);
+int orc_get_threads(void);
 void orc_cost_rows_f32(const orc_problem *p, const float *rows, int count,
                        double *cost, double *terms /* may be NULL, [count][3] */);
 double orc_toy_cost(double x, double y);

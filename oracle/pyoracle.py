@@ -98,6 +98,7 @@ def load():
         f = getattr(L, "orc_chol_" + name)
         f.argtypes, f.restype = [vp], c_double_p
     L.orc_lmcma_done.argtypes = [vp]
+    L.orc_lmcma_done.restype = i
     for name in ("lambda", "mu", "m", "itr", "iterator_sz", "counteval"):
         f = getattr(L, "orc_lmcma_" + name)
         f.argtypes, f.restype = [vp], i
@@ -113,6 +114,9 @@ def load():
     L.orc_cost.argtypes = [ctypes.POINTER(ProblemC), c_double_p, c_double_p]
     L.orc_cost.restype = d
     L.orc_cost_rows_f32.argtypes = [ctypes.POINTER(ProblemC), c_float_p, i, c_double_p, c_double_p]
+    L.orc_lmcma_run_trajectory.argtypes = [vp, ctypes.POINTER(ProblemC), i]
+    L.orc_set_threads.argtypes = [i]
+    L.orc_get_threads.restype = i
     L.orc_toy_cost.argtypes = [d, d]
     L.orc_toy_cost.restype = d
     L.orc_two_bar_map.argtypes = [i, i, c_u8_p]
@@ -328,6 +332,10 @@ class OracleLMCMA:
         assert rows.shape == (self.lam, self.N)
         self.L.orc_lmcma_set_arx(self.h, _dp(rows))
 
+    def run_trajectory(self, cost_oracle, generations):
+        """generations of ask / score (fp64 cost of the float-rounded rows) / tell, all in C."""
+        self.L.orc_lmcma_run_trajectory(self.h, ctypes.byref(cost_oracle.p), int(generations))
+
     def _arr(self, name, shape, dtype=np.float64):
         p = getattr(self.L, "orc_lmcma_" + name)(self.h)
         return np.ctypeslib.as_array(p, shape=shape).copy()
@@ -375,6 +383,10 @@ class OracleLMCMA:
     @property
     def sorted_fitness(self):
         return self._arr("sorted_fitness", (self.lam,))
+
+    def done(self):
+        """LMCMA::isBehaviorLearningDone (lmcma.cpp:426-429): sigma < 1e-20."""
+        return bool(self.L.orc_lmcma_done(self.h))
 
     def scalar(self, name):
         return getattr(self.L, "orc_lmcma_" + name)(self.h)
@@ -434,6 +446,11 @@ class CostOracle:
         terms = np.empty((n, 3))
         self.L.orc_cost_rows_f32(ctypes.byref(self.p), rows.ctypes.data_as(c_float_p), n, _dp(cost), _dp(terms))
         return cost, terms
+
+
+def set_threads(n):
+    """Host threads for the oracle's loops over candidates (results do not depend on it)."""
+    load().orc_set_threads(int(n))
 
 
 def toy_cost(x, y):

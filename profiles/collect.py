@@ -6,7 +6,8 @@
 Writes profiles/<tag>_kernel_stats.csv (the --kernel-trace --stats summary as is),
 profiles/<tag>_hbm_traffic.csv (per kernel: launches, mean FETCH_SIZE and WRITE_SIZE
 in KB per launch as the counters report them, and the corrected bytes per launch) and
-profiles/traffic_cfg2.json (corrected bytes per launch per kernel class, read by bench.py).
+profiles/traffic_cfg2.json (corrected bytes per launch per kernel class and their sum per
+generation, read by bench.py).
 Correction: FETCH_SIZE on gfx950 reports half the bytes of wide (16 B/lane) coalesced
 streaming reads, which is how these kernels read everything of any size, so
 bytes = 2 * FETCH_SIZE + WRITE_SIZE (both in KB of 1024 bytes).  Narrower reads (the
@@ -56,6 +57,7 @@ def main():
                 out.write("%s,%d,%.3f,%.3f,%.0f\n" % (k, fe[k][0], f_kb, w_kb, (2 * f_kb + w_kb) * 1024.0))
                 if k in CLASS_OF:
                     per_class[CLASS_OF[k]] += (2 * f_kb + w_kb) * 1024.0
+        per_class["generation"] = sum(per_class.values())   # all launches of one generation together
         json.dump({k: round(v) for k, v in per_class.items()}, open(os.path.join(HERE, "traffic_cfg2.json"), "w"),
                   indent=1, sort_keys=True)
 

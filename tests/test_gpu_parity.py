@@ -459,6 +459,65 @@ def test_graph_run_equals_phase_by_phase_run(hip, lam, m):
     assert a["sigma"] == b["sigma"] and a["best_f"] == b["best_f"]
 
 
+def test_stop_rule_fires_in_the_oracles_generation_and_freezes_the_state(hip, oracle):
+    """LMCMA::isBehaviorLearningDone (lmcma.cpp:426-429: sigma < 1e-20) evaluated by the update
+    kernel.  Float rows resolve a step size of 1e-20 only around the origin, so the problem is a
+    closed path through the origin on an empty map, started at its optimum with sigma = 2e-19: no
+    generation improves on the last one, the success rule shrinks sigma, and the oracle (handed the
+    device's rows and costs) and the device must cross 1e-20 in the same generation."""
+    W, N, lam, m = 8, 16, 32, 4
+    start = goal = [0.0, 0.0]
+    ctx = hip.HipContext(N, lam, m, dims=2, waypoints=W, start=start, goal=goal, seed=5)
+    ctx.set_grid(np.zeros((8, 8), dtype=np.uint8))
+    lo, hi = np.full(N, -1.0), np.full(N, 1.0)
+    ctx.set_bounds(lo, hi)
+    ctx.opt_init(np.zeros(N), 2e-19)
+    o = oracle.OracleLMCMA(N, lam, m, initial=np.zeros(N), lo=lo, hi=hi, sigma=2e-19, seed=5, z_source=oracle.Z_GIVEN)
+    fired = None
+    for g in range(200):
+        ctx.phase_local()
+        rows, costs = ctx.rows(), ctx.costs()
+        assert np.unique(costs).size > lam // 2          # the costs resolve the candidates: no mass of ties
+        ctx.phase_rank()
+        ctx.phase_update(0)
+        o.set_arx(rows)
+        o.update_only(costs)
+        st = ctx.opt_get()
+        np.testing.assert_allclose(st["sigma"], o.sigma, rtol=1e-11)
+        assert st["done"] == o.done(), (g, st["sigma"], o.sigma)
+        if st["done"]:
+            fired = g + 1
+            break
+    assert fired is not None and fired == st["itr"] and st["sigma"] < 1e-20
+    # generations queued beyond the stop change nothing
+    vec = ctx.opt_vectors()
+    ctx.run(20)
+    for _ in range(3):
+        ctx.phase_local()
+        ctx.phase_rank()
+        ctx.phase_update(0)
+    st2, vec2 = ctx.opt_get(), ctx.opt_vectors()
+    assert st2["done"] and st2["itr"] == fired and st2["sigma"] == st["sigma"] and st2["counteval"] == st["counteval"]
+    np.testing.assert_array_equal(st2["xmean"], st["xmean"])
+    np.testing.assert_array_equal(vec2["v_arr"], vec["v_arr"])
+    # a new query starts live again
+    ctx.opt_reset()
+    ctx.run(3)
+    st3 = ctx.opt_get()
+    assert not st3["done"] and st3["itr"] == 3
+    ctx.close()
+    # the class: step(n) returns at the stop and isBehaviorLearningDone reports it
+    from lmcma_path_planner_amd import LMCMA
+    opt = LMCMA(np.zeros(N), lam, lo, hi, 2e-19, None, 5)
+    opt.setOptions(m=m, philox=True, device_update=True)
+    opt.setTrajectoryProblem(2, W, np.zeros((8, 8), dtype=np.uint8), start, goal)
+    opt.init(N)
+    assert not opt.isBehaviorLearningDone()
+    opt.step(5000)
+    assert opt.isBehaviorLearningDone() and opt.generation < 200 and opt.counteval == opt.generation * lam
+    opt.close()
+
+
 def _run_both(hip, oracle, N, W, lam, m, occ, start, goal, x0, lo, hi, sigma0, gens, seed):
     co = oracle.CostOracle(2, W, occ, start, goal)
     o = oracle.OracleLMCMA(N, lam, m, initial=x0, lo=lo, hi=hi, sigma=sigma0, seed=seed, z_source=oracle.Z_PHILOX)
