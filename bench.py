@@ -86,6 +86,46 @@ def cpu_baseline(prob, threads, budget_s):
                       % (gens, prob.lam, el, threads, "" if threads == 1 else "s over the candidates")}
 
 
+def batched_leg(hip, prob, lam, queries, steps):
+    """The same workload with `queries` independent optimisers (restarts with their own seeds) in
+    one context: every launch advances all of them.  Not the headline: reported beside it."""
+    ctx = hip.HipContext(prob.N, lam, prob.m, dims=prob.dims, waypoints=prob.W, seed=42, start=prob.start,
+                         goal=prob.goal, w_len=prob.weights[0], w_grid=prob.weights[1], w_smooth=prob.weights[2],
+                         queries=queries)
+    ctx.set_grid(prob.cells)
+    ctx.set_bounds(prob.lo, prob.hi)
+    ctx.opt_init(prob.x0, prob.sigma0)
+
+    def run_steps(k):
+        done = 0
+        while done < k:
+            n = min(EPISODE, k - done)
+            ctx.opt_reset()
+            ctx.run(n)
+            done += n
+
+    run_steps(12)
+    ctx.synchronize()
+    run_steps(100)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.stream_mark(0)
+    run_steps(steps)
+    ctx.stream_mark(1)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    device_ms = ctx.stream_elapsed()
+    ctx.close()
+    b_cand = prob.algorithmic_bytes_per_candidate(lam)
+    value = queries * lam * steps / elapsed
+    achieved = b_cand * lam * queries / (device_ms * 1e-3 / steps) / 1e9
+    return {"queries_in_flight": queries, "value": value, "unit": "candidate-trajectories/s", "steps": steps,
+            "ms_per_step": elapsed / steps * 1e3, "us_per_generation_per_query": device_ms * 1e3 / steps / queries,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS},
+            "note": "independent restarts of the same planning problem (own Philox keys) advanced by every launch"}
+
+
 def host_threads():
     """Host threads of this job's CPU share: OMP_NUM_THREADS when the box sets it, else the
     affinity mask, at most 16."""
@@ -105,6 +145,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", type=int, default=2, help="benchmark configuration (2 = the headline one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--queries", type=int, default=1,
+                    help="independent optimisers (restarts of the planning problem, own seeds) advanced together by "
+                    "every launch of one context; 1 = the configuration as named")
+    ap.add_argument("--batched-queries", type=int, default=16,
+                    help="after the headline measurement, also measure this many queries in one context (0: skip)")
     ap.add_argument("--structured-covariance", action="store_true",
                     help="sample with the smoothness covariance of the reference (z <- L z on the matrix cores); "
                     "not the headline workload")
@@ -145,7 +190,7 @@ def main():
     ctx = hip.HipContext(prob.N, lam_total, prob.m, dims=prob.dims, waypoints=prob.W, lambda_local=lam_local,
                          first_candidate=rank * lam_local, seed=42, start=prob.start, goal=prob.goal,
                          w_len=prob.weights[0], w_grid=prob.weights[1], w_smooth=prob.weights[2],
-                         device=local_rank, stream=stream)
+                         device=local_rank, stream=stream, queries=args.queries)
     ctx.set_grid(prob.cells)
     ctx.set_bounds(prob.lo, prob.hi)
     if args.structured_covariance:
@@ -231,7 +276,7 @@ def main():
         # the timed region / K (events on the library's stream).  That chain is what the roofline
         # fraction is quoted for: no single kernel of it moves the generation's bytes.
         b_cand = prob.algorithmic_bytes_per_candidate(lam_local)
-        gen_bytes = b_cand * lam_local
+        gen_bytes = b_cand * lam_local * args.queries
         gen_us = device_ms * 1e3 / args.steps
         achieved = gen_bytes / (gen_us * 1e-6) / 1e9
         traffic = None
@@ -241,7 +286,7 @@ def main():
             traffic = tj.get("generation")
         out = {
             "metric": "candidate-trajectories/sec (lambda x gens/s), 512^2 grid, 64-waypoint",
-            "value": lam_total * args.steps / elapsed,
+            "value": args.queries * lam_total * args.steps / elapsed,
             "unit": "candidate-trajectories/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -254,7 +299,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": prob.name + ("+structured-covariance" if args.structured_covariance else ""), "grid": "x".join(str(s) for s in prob.cells.shape),
                        "waypoints": prob.W, "n_params": prob.N, "lambda_per_gpu": lam_local,
-                       "lambda_total": lam_total, "m": prob.m, "z_source": "philox4x32-10",
+                       "lambda_total": lam_total, "m": prob.m, "queries_in_flight": args.queries,
+                       "z_source": "philox4x32-10",
                        "update": "on device, fp64", "episode_generations": EPISODE, "exchange": "all-gather of sorted local costs + all-gather of elite partial sums (N+2 doubles per rank)"
                        if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "one generation: " + " + ".join(k for k in per_kernel),
@@ -268,6 +314,8 @@ def main():
                                "eager_pass_us_per_step": eager_ms * 1e3 / timed_steps},
             "final": {"generations": st["itr"], "best_f": st["best_f"], "sigma": st["sigma"]},
         }
+        if world == 1 and args.queries == 1 and args.batched_queries > 1:
+            out["batched_queries"] = batched_leg(hip, prob, lam_local, args.batched_queries, max(args.steps, 400))
         if world == 1 and not args.no_cpu_baseline:
             cores = host_threads()
             out["cpu_baseline"] = cpu_baseline(prob, cores, 12.0)

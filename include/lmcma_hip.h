@@ -50,6 +50,7 @@ enum { LMCMA_COST_TRAJECTORY = 0, LMCMA_COST_EXTERNAL = 1 };
 #define LMCMA_HIP_MAX_VECTORS 64            /* device-resident update (lmcma_hip_opt_init)   */
 #define LMCMA_HIP_MAX_VECTORS_STEPWISE 4096 /* stepwise API: the caller keeps the state      */
 #define LMCMA_HIP_MAX_LAMBDA (1 << 20)
+#define LMCMA_HIP_MAX_QUERIES 256
 
 typedef struct lmcma_hip_ctx lmcma_hip_ctx;
 
@@ -68,8 +69,9 @@ typedef struct {
     int32_t z_source;        /* LMCMA_Z_HOST or LMCMA_Z_PHILOX                       */
     int32_t cost_source;     /* LMCMA_COST_TRAJECTORY or LMCMA_COST_EXTERNAL         */
     int32_t pad_mode;        /* acceleration stencil at the path ends                */
-    int32_t reserved;
-    uint64_t seed;           /* Philox key                                           */
+    int32_t queries;         /* independent optimisers in this context (0 = 1), see  */
+                             /* "several queries in one context" below               */
+    uint64_t seed;           /* Philox key (query q draws from seed + q)             */
     double w_len, w_grid, w_smooth;
     double start[3], goal[3];
     void *stream;            /* hipStream_t to run on; NULL: the context makes one   */
@@ -209,6 +211,24 @@ int lmcma_hip_opt_reset(lmcma_hip_ctx *ctx);
  * nothing and lmcma_hip_opt_summary.itr is the generation that reached it.
  * The first call on a context also records the HIP graphs later calls replay. */
 int lmcma_hip_run(lmcma_hip_ctx *ctx, int n_generations);
+
+/* ---- several queries in one context ------------------------------------------------
+ * One optimiser's generation is a chain of three dependent launches that leaves most of the
+ * GPU idle.  A context created with queries = Q > 1 holds Q independent optimisers on the same
+ * map, start, goal, bounds and sizes (restarts of one planning problem from different seeds or
+ * initial paths: the reference's caller would run its ask/tell loop Q times, L/example_lmcma.cpp:
+ * 47-60) and advances all of them with every launch: lmcma_hip_run(ctx, n) = n generations of
+ * each.  Query q samples from the Philox key seed + q, so it is the run a one-query context
+ * with that seed makes, bit for bit.  Needs lambda_local == lambda_total <= 16384, z_source
+ * PHILOX, cost_source TRAJECTORY, m <= 64; the stepwise calls (set_state ... recombine) are not
+ * available.  lmcma_hip_opt_init starts every query from the same mean and step size;
+ * lmcma_hip_opt_set_query gives one query its own (and puts that query back to generation 0).
+ * The stop rule freezes each query on its own.  The readers (get_rows, get_costs, get_terms,
+ * opt_get, opt_get_vectors, buffer) address the query chosen by lmcma_hip_query_select
+ * (0 at creation).                                                                        */
+int lmcma_hip_opt_set_query(lmcma_hip_ctx *ctx, int query, const double *xmean0, double sigma0);
+int lmcma_hip_query_select(lmcma_hip_ctx *ctx, int query);
+int lmcma_hip_queries(lmcma_hip_ctx *ctx);
 
 /* The same generation in pieces, for a population sharded over contexts:
  *   phase_local   : sample + evaluate own candidates  -> LMCMA_BUF_COST_LOCAL

@@ -35,7 +35,7 @@ class HipConfig(ctypes.Structure):
         ("z_source", ctypes.c_int32),
         ("cost_source", ctypes.c_int32),
         ("pad_mode", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("queries", ctypes.c_int32),
         ("seed", ctypes.c_uint64),
         ("w_len", ctypes.c_double),
         ("w_grid", ctypes.c_double),
@@ -100,6 +100,9 @@ SIGNATURES = {
     "lmcma_hip_score_rows": (_i, [_vp, c_float_p, _i, c_float_p, c_float_p]),
     "lmcma_hip_opt_init": (_i, [_vp, c_double_p, ctypes.c_double]),
     "lmcma_hip_opt_reset": (_i, [_vp]),
+    "lmcma_hip_opt_set_query": (_i, [_vp, _i, c_double_p, ctypes.c_double]),
+    "lmcma_hip_query_select": (_i, [_vp, _i]),
+    "lmcma_hip_queries": (_i, [_vp]),
     "lmcma_hip_run": (_i, [_vp, _i]),
     "lmcma_hip_phase_local": (_i, [_vp]),
     "lmcma_hip_phase_rank": (_i, [_vp]),

@@ -11,7 +11,7 @@
 #include <string>
 #include <vector>
 
-#include "device_types.hpp"
+#include "device_funcs.hpp"
 
 using namespace lmcma;
 
@@ -74,10 +74,14 @@ __global__ void k_set_sample_scalars(SampleScalars *sc, float sigma, float mk, i
 }
 
 // back to the state lmcma_hip_opt_init left: mean, step size, empty direction store
-__global__ void k_opt_reset(OptScalars *opt, SampleScalars *sc, const double *xmean0, double sigma0,
+__global__ void k_opt_reset(OptScalars *opt, SampleScalars *sc, const double *xmean0,
                             double *xmean, float *xmean_f, double *pc, int N, int ld,
-                            unsigned long long *psr_accum)
+                            unsigned long long *psr_accum, size_t qstride)
 {
+    const size_t off = (size_t)blockIdx.y * qstride;  // query blockIdx.y of a batch
+    shift_ptr(opt, off); shift_ptr(sc, off); shift_ptr(xmean0, off); shift_ptr(xmean, off);
+    shift_ptr(xmean_f, off); shift_ptr(pc, off); shift_ptr(psr_accum, off);
+    const double sigma0 = opt->sigma0;
     for (int n = threadIdx.x; n < ld; n += blockDim.x) {
         const double x = n < N ? xmean0[n] : 0.0;
         if (n < N) {
@@ -117,6 +121,10 @@ constexpr int kGensPerGraph[2] = {8, 2};
 struct lmcma_hip_ctx {
     lmcma_hip_config cfg{};
     int N = 0, ld = 0, D = 0, W = 0, lambda = 0, nloc = 0, first = 0, m = 0, mu = 0;
+    // Q independent optimisers in this context (see Batch): every arena buffer exists Q times, qstride
+    // bytes apart; the pointers below are query 0's.  qsel: the query the reader functions address.
+    int Q = 1, qsel = 0, pending_rows = 0;
+    size_t qstride = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
 
@@ -199,10 +207,13 @@ struct Arena {
     {
         req.push_back({reinterpret_cast<void **>(p), (count * sizeof(T) + 16 + 255) & ~(size_t)255});
     }
-    hipError_t commit(void **base)
+    // copies: the whole set of buffers that many times, *stride bytes apart (the pointers are those of copy 0)
+    hipError_t commit(void **base, int copies, size_t *stride)
     {
         size_t total = 0;
         for (auto &r : req) total += r.second;
+        *stride = total;
+        total *= (size_t)copies;
         hipError_t e = hipMalloc(base, total);
         if (e == hipSuccess) e = hipMemset(*base, 0, total);
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // see dalloc
@@ -263,6 +274,17 @@ struct Timed {
         if (ev) (void)hipEventRecord(ev->b, c->stream);
     }
 };
+
+// query q's copy of a context buffer, and the copy the reader functions address
+template <typename T>
+T *query_ptr(const lmcma_hip_ctx *c, T *p, int q)
+{
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(p) + (size_t)q * c->qstride);
+}
+template <typename T>
+T *sel(const lmcma_hip_ctx *c, T *p) { return query_ptr(c, p, c->qsel); }
+
+Batch batch_of(const lmcma_hip_ctx *c) { return Batch{c->Q, c->Q > 1 ? c->qstride : 0}; }
 
 // where the kernels leave the costs of the local candidates, in candidate order
 float *local_costs(const lmcma_hip_ctx *c) { return c->merge_protocol ? c->cost_raw : c->cost_all + c->first; }
@@ -326,6 +348,7 @@ int do_generate(lmcma_hip_ctx *c)
     g.key1 = (uint32_t)(c->cfg.seed >> 32);
     g.cost = cost_params(c, c->rows, c->nloc, local_costs(c), c->terms);
     if (c->have_cov) g.cov = c->cov;
+    g.batch = batch_of(c);
     HIP_TRY(launch_generate(c->stream, g, c->D, c->grid_lds));
     c->sampled = true;
     return LMCMA_HIP_OK;
@@ -352,6 +375,7 @@ UpdateArgs update_args(const lmcma_hip_ctx *c, const double *partials, int n_par
     a.nj = c->nj; a.lj = c->lj;
     a.t = c->t; a.vec = c->vec; a.iterator = c->iterator;
     a.xmean_f = c->xmean_f; a.V_f = c->V_f; a.B_f = c->B_f;
+    a.batch = batch_of(c);
     return a;
 }
 
@@ -375,6 +399,7 @@ int do_select(lmcma_hip_ctx *c, bool with_recombine, int *rows_out, bool with_pr
     a.prev_sorted = c->sorted_buf[c->parity ^ 1];
     a.psr_accum = c->psr_accum;
     a.rc = recombine ? &rc : nullptr;
+    a.batch = batch_of(c);
     const UpdateArgs pre = update_args(c, nullptr, 0, false);
     a.pre = (with_pre && c->opt_ready && !c->pre_done) ? &pre : nullptr;
     SelectResult res{};
@@ -403,7 +428,7 @@ int reduce_if_many(lmcma_hip_ctx *c, int *rows, const double **src)
     *src = c->block_partials;
     if (*rows < kReduceRowsFrom) return LMCMA_HIP_OK;
     Timed tm(c, LMCMA_K_RECOMBINE);
-    HIP_TRY(launch_reduce_rows(c->stream, c->block_partials, *rows, c->N, c->reduced_rows));
+    HIP_TRY(launch_reduce_rows(c->stream, c->block_partials, *rows, c->N, c->reduced_rows, batch_of(c)));
     *src = c->reduced_rows;
     *rows = reduce_rows_out(*rows);
     return LMCMA_HIP_OK;
@@ -530,6 +555,15 @@ int lmcma_hip_create(const lmcma_hip_config *cfg, lmcma_hip_ctx **out)
     if (cfg->mu < 1 || cfg->mu > cfg->lambda_total) return fail(LMCMA_HIP_ERR_ARG, "mu must be in [1, lambda]");
     if (cfg->z_source != LMCMA_Z_HOST && cfg->z_source != LMCMA_Z_PHILOX)
         return fail(LMCMA_HIP_ERR_ARG, "unknown z_source");
+    const int queries = cfg->queries == 0 ? 1 : cfg->queries;
+    if (queries < 1 || queries > LMCMA_HIP_MAX_QUERIES)
+        return fail(LMCMA_HIP_ERR_UNSUPPORTED, "queries must be in [1, 256]");
+    if (queries > 1 && (cfg->lambda_local != cfg->lambda_total || cfg->z_source != LMCMA_Z_PHILOX ||
+                        cfg->cost_source != LMCMA_COST_TRAJECTORY || !select_by_counting(cfg->lambda_total) ||
+                        cfg->m > LMCMA_HIP_MAX_VECTORS))
+        return fail(LMCMA_HIP_ERR_UNSUPPORTED,
+                    "several queries in one context: the whole population of each in the context (lambda_local = "
+                    "lambda_total <= 16384), z_source PHILOX, cost_source TRAJECTORY, m <= 64");
 
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -554,6 +588,7 @@ int lmcma_hip_create(const lmcma_hip_config *cfg, lmcma_hip_ctx **out)
     c->first = cfg->first_candidate;
     c->m = cfg->m;
     c->mu = cfg->mu;
+    c->Q = queries;
     if (cfg->stream) {
         c->stream = (hipStream_t)cfg->stream;
     } else {
@@ -603,21 +638,23 @@ int lmcma_hip_create(const lmcma_hip_config *cfg, lmcma_hip_ctx **out)
     ar.add(&c->reduced_rows, (size_t)kReducedRowsMax * N);
     ar.add(&c->terms, nloc * 3);
     ar.add(&c->rows, nloc * ld);
-    hipError_t e = ar.commit(&c->arena);
+    hipError_t e = ar.commit(&c->arena, c->Q, &c->qstride);
     auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     c->sorted_cost = c->sorted_buf[0];
     if (e == hipSuccess) {
         // no bounds until set_bounds: -inf / +inf
         std::vector<float> lo(ld, -INFINITY), hi(ld, INFINITY);
-        A(hipMemcpy(c->lo_f, lo.data(), ld * sizeof(float), hipMemcpyHostToDevice));
-        A(hipMemcpy(c->hi_f, hi.data(), ld * sizeof(float), hipMemcpyHostToDevice));
+        for (int q = 0; q < c->Q; ++q) {
+            A(hipMemcpy(query_ptr(c, c->lo_f, q), lo.data(), ld * sizeof(float), hipMemcpyHostToDevice));
+            A(hipMemcpy(query_ptr(c, c->hi_f, q), hi.data(), ld * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     if (e != hipSuccess) {
         std::string msg = std::string("device allocation failed: ") + hipGetErrorString(e);
         lmcma_hip_destroy(c);
         return fail(LMCMA_HIP_ERR_RUNTIME, msg);
     }
-    if (const char *f = getenv("LMCMA_HIP_FUSED")) c->fused = f[0] != '0';
+    if (const char *f = getenv("LMCMA_HIP_FUSED")) c->fused = f[0] != '0' || c->Q > 1;
     *out = c;
     return LMCMA_HIP_OK;
 }
@@ -781,8 +818,10 @@ int lmcma_hip_set_bounds(lmcma_hip_ctx *c, const double *lo, const double *hi)
         }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(c->lo_f, l.data(), c->ld * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->hi_f, h.data(), c->ld * sizeof(float), hipMemcpyHostToDevice));
+    for (int q = 0; q < c->Q; ++q) {  // the same box for every query
+        HIP_TRY(hipMemcpy(query_ptr(c, c->lo_f, q), l.data(), c->ld * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(query_ptr(c, c->hi_f, q), h.data(), c->ld * sizeof(float), hipMemcpyHostToDevice));
+    }
     return LMCMA_HIP_OK;
 }
 
@@ -790,6 +829,7 @@ int lmcma_hip_set_state(lmcma_hip_ctx *c, const double *xmean, double sigma, con
                         const double *PC, const double *nj, int k, double M)
 {
     CTX_TRY(c);
+    if (c->Q > 1) return fail(LMCMA_HIP_ERR_STATE, "set_state: the stepwise calls serve one query per context");
     if (!xmean) return fail(LMCMA_HIP_ERR_ARG, "xmean is null");
     if (k < 0 || k > c->m) return fail(LMCMA_HIP_ERR_ARG, "k must be in [0, m]");
     if (k > 0 && (!V || !PC || !nj)) return fail(LMCMA_HIP_ERR_ARG, "V, PC and nj are needed when k > 0");
@@ -856,6 +896,7 @@ int lmcma_hip_set_cov_factor(lmcma_hip_ctx *c, const double *L)
 int lmcma_hip_sample(lmcma_hip_ctx *c, uint32_t generation, const double *z_host)
 {
     CTX_TRY(c);
+    if (c->Q > 1) return fail(LMCMA_HIP_ERR_STATE, "sample: the stepwise calls serve one query per context");
     if (!c->have_state && !c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "set_state or opt_init must come first");
     if (c->cfg.z_source == LMCMA_Z_HOST && !z_host)
         return fail(LMCMA_HIP_ERR_ARG, "z_source HOST needs z_host");
@@ -883,6 +924,7 @@ int lmcma_hip_sample(lmcma_hip_ctx *c, uint32_t generation, const double *z_host
 int lmcma_hip_evaluate(lmcma_hip_ctx *c)
 {
     CTX_TRY(c);
+    if (c->Q > 1) return fail(LMCMA_HIP_ERR_STATE, "evaluate: the stepwise calls serve one query per context");
     if (c->cfg.cost_source != LMCMA_COST_TRAJECTORY)
         return fail(LMCMA_HIP_ERR_STATE, "cost_source is EXTERNAL: use lmcma_hip_set_costs");
     if (!c->grid) return fail(LMCMA_HIP_ERR_STATE, "set_grid must come first");
@@ -898,6 +940,7 @@ int lmcma_hip_evaluate(lmcma_hip_ctx *c)
 int lmcma_hip_set_costs(lmcma_hip_ctx *c, int first, int count, const double *costs)
 {
     CTX_TRY(c);
+    if (c->Q > 1) return fail(LMCMA_HIP_ERR_STATE, "set_costs: the stepwise calls serve one query per context");
     if (!costs || first < 0 || count < 1 || first + count > c->lambda)
         return fail(LMCMA_HIP_ERR_ARG, "bad candidate range");
     std::vector<float> f(count);
@@ -913,6 +956,7 @@ int lmcma_hip_select(lmcma_hip_ctx *c, float *sorted_cost, int32_t *perm)
     CTX_TRY(c);
     // a context that holds the whole population knows whether it has this generation's costs (a
     // shard's other costs arrive through LMCMA_BUF_COST_ALL, which the library cannot see)
+    if (c->Q > 1) return fail(LMCMA_HIP_ERR_STATE, "select: the stepwise calls serve one query per context");
     if (c->nloc == c->lambda && !c->costs_ready)
         return fail(LMCMA_HIP_ERR_STATE, "select: no costs yet (evaluate or set_costs must come first)");
     int rc = do_select(c, false, nullptr);
@@ -928,6 +972,7 @@ int lmcma_hip_select(lmcma_hip_ctx *c, float *sorted_cost, int32_t *perm)
 int lmcma_hip_recombine(lmcma_hip_ctx *c, const double *weights, double *xmean_out)
 {
     CTX_TRY(c);
+    if (c->Q > 1) return fail(LMCMA_HIP_ERR_STATE, "recombine: the stepwise calls serve one query per context");
     if (!c->selected) return fail(LMCMA_HIP_ERR_STATE, "select must come first");
     if (weights) {
         HIP_TRY(hipMemcpyAsync(c->weights, weights, c->mu * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -950,7 +995,7 @@ int lmcma_hip_get_rows(lmcma_hip_ctx *c, int first_local, int count, double *out
     if (!out || first_local < 0 || count < 1 || first_local + count > c->nloc)
         return fail(LMCMA_HIP_ERR_ARG, "bad candidate range");
     std::vector<float> tmp((size_t)count * c->ld);
-    HIP_TRY(hipMemcpyAsync(tmp.data(), c->rows + (size_t)first_local * c->ld, tmp.size() * sizeof(float),
+    HIP_TRY(hipMemcpyAsync(tmp.data(), sel(c, c->rows) + (size_t)first_local * c->ld, tmp.size() * sizeof(float),
                            hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < count; ++i)
@@ -964,7 +1009,7 @@ int lmcma_hip_get_costs(lmcma_hip_ctx *c, int first_local, int count, double *ou
     if (!out || first_local < 0 || count < 1 || first_local + count > c->nloc)
         return fail(LMCMA_HIP_ERR_ARG, "bad candidate range");
     std::vector<float> tmp(count);
-    HIP_TRY(hipMemcpyAsync(tmp.data(), local_costs(c) + first_local, count * sizeof(float),
+    HIP_TRY(hipMemcpyAsync(tmp.data(), sel(c, local_costs(c)) + first_local, count * sizeof(float),
                            hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < count; ++i) out[i] = (double)tmp[i];
@@ -977,7 +1022,7 @@ int lmcma_hip_get_terms(lmcma_hip_ctx *c, int first_local, int count, double *ou
     if (!out3 || first_local < 0 || count < 1 || first_local + count > c->nloc)
         return fail(LMCMA_HIP_ERR_ARG, "bad candidate range");
     std::vector<float> tmp((size_t)count * 3);
-    HIP_TRY(hipMemcpyAsync(tmp.data(), c->terms + (size_t)first_local * 3, tmp.size() * sizeof(float),
+    HIP_TRY(hipMemcpyAsync(tmp.data(), sel(c, c->terms) + (size_t)first_local * 3, tmp.size() * sizeof(float),
                            hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < tmp.size(); ++i) out3[i] = (double)tmp[i];
@@ -1048,24 +1093,28 @@ int lmcma_hip_opt_init(lmcma_hip_ctx *c, const double *xmean0, double sigma0)
     o.val_target = 0.25;                       // lmcma.cpp:238
     o.K = 1 / sqrt(1 - o.c1);
     o.M = sqrt(1 - o.c1);
-    HIP_TRY(hipMemcpy(c->opt, &o, sizeof(o), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->weights, w.data(), mu * sizeof(double), hipMemcpyHostToDevice));
-    c->have_weights = true;
-    HIP_TRY(hipMemcpy(c->xmean, xmean0, N * sizeof(double), hipMemcpyHostToDevice));
+    o.sigma0 = sigma0;
     std::vector<float> xm(c->ld, 0.f);
     for (int n = 0; n < N; ++n) xm[n] = (float)xmean0[n];
-    HIP_TRY(hipMemcpy(c->xmean_f, xm.data(), c->ld * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(c->pc, 0, N * sizeof(double)));
-    HIP_TRY(hipMemset(c->pc_arr, 0, (size_t)m * N * sizeof(double)));
-    HIP_TRY(hipMemset(c->v_arr, 0, (size_t)m * N * sizeof(double)));
-    HIP_TRY(hipMemset(c->nj, 0, m * sizeof(double)));
-    HIP_TRY(hipMemset(c->lj, 0, m * sizeof(double)));
-    HIP_TRY(hipMemset(c->t, 0, m * sizeof(int32_t)));
-    HIP_TRY(hipMemset(c->vec, 0, m * sizeof(int32_t)));
-    HIP_TRY(hipMemset(c->iterator, 0, m * sizeof(int32_t)));
     SampleScalars sc{(float)sigma0, 1.0f, 0, 0u};
-    HIP_TRY(hipMemcpy(c->sc, &sc, sizeof(sc), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->xmean0, xmean0, N * sizeof(double), hipMemcpyHostToDevice));
+    for (int q = 0; q < c->Q; ++q) {  // every query starts from the same mean and step size (opt_set_query changes one)
+        HIP_TRY(hipMemcpy(query_ptr(c, c->opt, q), &o, sizeof(o), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(query_ptr(c, c->weights, q), w.data(), mu * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(query_ptr(c, c->xmean, q), xmean0, N * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(query_ptr(c, c->xmean_f, q), xm.data(), c->ld * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(query_ptr(c, c->pc, q), 0, N * sizeof(double)));
+        HIP_TRY(hipMemset(query_ptr(c, c->pc_arr, q), 0, (size_t)m * N * sizeof(double)));
+        HIP_TRY(hipMemset(query_ptr(c, c->v_arr, q), 0, (size_t)m * N * sizeof(double)));
+        HIP_TRY(hipMemset(query_ptr(c, c->nj, q), 0, m * sizeof(double)));
+        HIP_TRY(hipMemset(query_ptr(c, c->lj, q), 0, m * sizeof(double)));
+        HIP_TRY(hipMemset(query_ptr(c, c->t, q), 0, m * sizeof(int32_t)));
+        HIP_TRY(hipMemset(query_ptr(c, c->vec, q), 0, m * sizeof(int32_t)));
+        HIP_TRY(hipMemset(query_ptr(c, c->iterator, q), 0, m * sizeof(int32_t)));
+        HIP_TRY(hipMemset(query_ptr(c, c->psr_accum, q), 0, sizeof(unsigned long long)));
+        HIP_TRY(hipMemcpy(query_ptr(c, c->sc, q), &sc, sizeof(sc), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(query_ptr(c, c->xmean0, q), xmean0, N * sizeof(double), hipMemcpyHostToDevice));
+    }
+    c->have_weights = true;
     HIP_TRY(hipStreamSynchronize(nullptr));  // the fills above: done before the context's stream is used
     c->sigma0 = sigma0;
     c->opt_ready = true;
@@ -1079,11 +1128,40 @@ int lmcma_hip_opt_reset(lmcma_hip_ctx *c)
     CTX_TRY(c);
     if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
     c->pre_done = false;
-    hipLaunchKernelGGL(k_opt_reset, dim3(1), dim3(256), 0, c->stream, c->opt, c->sc, c->xmean0, c->sigma0,
-                       c->xmean, c->xmean_f, c->pc, c->N, c->ld, c->psr_accum);
+    hipLaunchKernelGGL(k_opt_reset, dim3(1, c->Q), dim3(256), 0, c->stream, c->opt, c->sc, c->xmean0,
+                       c->xmean, c->xmean_f, c->pc, c->N, c->ld, c->psr_accum, c->qstride);
     HIP_TRY(hipGetLastError());
     return LMCMA_HIP_OK;
 }
+
+int lmcma_hip_opt_set_query(lmcma_hip_ctx *c, int query, const double *xmean0, double sigma0)
+{
+    CTX_TRY(c);
+    if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
+    if (query < 0 || query >= c->Q) return fail(LMCMA_HIP_ERR_ARG, "opt_set_query: no such query");
+    if (!xmean0 || !(sigma0 > 0.0)) return fail(LMCMA_HIP_ERR_ARG, "xmean0 and a positive sigma0 are needed");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(query_ptr(c, c->xmean0, query), xmean0, c->N * sizeof(double), hipMemcpyHostToDevice));
+    OptScalars *opt = query_ptr(c, c->opt, query);
+    HIP_TRY(hipMemcpy(&opt->sigma0, &sigma0, sizeof(double), hipMemcpyHostToDevice));
+    // that query alone goes back to its (new) initial state
+    hipLaunchKernelGGL(k_opt_reset, dim3(1, 1), dim3(256), 0, c->stream, opt, query_ptr(c, c->sc, query),
+                       query_ptr(c, c->xmean0, query), query_ptr(c, c->xmean, query), query_ptr(c, c->xmean_f, query),
+                       query_ptr(c, c->pc, query), c->N, c->ld, query_ptr(c, c->psr_accum, query), (size_t)0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_query_select(lmcma_hip_ctx *c, int query)
+{
+    if (!c) return fail(LMCMA_HIP_ERR_ARG, "null context");
+    if (query < 0 || query >= c->Q) return fail(LMCMA_HIP_ERR_ARG, "query_select: no such query");
+    c->qsel = query;
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_queries(lmcma_hip_ctx *c) { return c ? c->Q : 0; }
 
 int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
 {
@@ -1202,6 +1280,11 @@ int lmcma_hip_phase_rank(lmcma_hip_ctx *c)
     }
     int rc = do_select(c, true, &rows, true);
     if (rc != LMCMA_HIP_OK) return rc;
+    if (c->Q > 1) {
+        // several queries: nothing leaves the context, the update adds the block rows itself
+        c->pending_rows = rows;
+        return rows > 0 ? LMCMA_HIP_OK : fail(LMCMA_HIP_ERR_STATE, "phase_rank: the ranking launch left no partial rows");
+    }
     if (rows > 0) return do_recombine_final(c, rows, true);
     rc = do_recombine(c);
     if (rc != LMCMA_HIP_OK) return rc;
@@ -1213,6 +1296,14 @@ int lmcma_hip_phase_update(lmcma_hip_ctx *c, int n_partials)
     CTX_TRY(c);
     if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
     if (n_partials < 0 || n_partials > kMaxPartials) return fail(LMCMA_HIP_ERR_ARG, "n_partials must be in [0, 64]");
+    if (c->Q > 1) {
+        if (n_partials != 0) return fail(LMCMA_HIP_ERR_ARG, "phase_update: a context with several queries is not a shard");
+        int rows = c->pending_rows;
+        const double *src = nullptr;
+        int rc = reduce_if_many(c, &rows, &src);
+        if (rc != LMCMA_HIP_OK) return rc;
+        return do_update(c, src, rows, false);
+    }
     // n_partials = 0: a single context, its own partial sum is the new mean
     if (n_partials == 0) return do_update(c, c->partial_local, 1, true);
     return do_update(c, c->partial_all, n_partials, true);
@@ -1223,8 +1314,8 @@ int lmcma_hip_opt_get(lmcma_hip_ctx *c, lmcma_hip_opt_summary *summary, double *
     CTX_TRY(c);
     if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
     OptScalars o;
-    HIP_TRY(hipMemcpyAsync(&o, c->opt, sizeof(o), hipMemcpyDeviceToHost, c->stream));
-    if (xmean) HIP_TRY(hipMemcpyAsync(xmean, c->xmean, c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&o, sel(c, c->opt), sizeof(o), hipMemcpyDeviceToHost, c->stream));
+    if (xmean) HIP_TRY(hipMemcpyAsync(xmean, sel(c, c->xmean), c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (summary) {
         summary->itr = o.itr;
@@ -1244,12 +1335,12 @@ int lmcma_hip_opt_get_vectors(lmcma_hip_ctx *c, double *pc, double *v_arr, doubl
 {
     CTX_TRY(c);
     const size_t N = c->N, m = c->m;
-    if (pc) HIP_TRY(hipMemcpyAsync(pc, c->pc, N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (v_arr) HIP_TRY(hipMemcpyAsync(v_arr, c->v_arr, m * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (pc_arr) HIP_TRY(hipMemcpyAsync(pc_arr, c->pc_arr, m * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (nj) HIP_TRY(hipMemcpyAsync(nj, c->nj, m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (lj) HIP_TRY(hipMemcpyAsync(lj, c->lj, m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (iterator) HIP_TRY(hipMemcpyAsync(iterator, c->iterator, m * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (pc) HIP_TRY(hipMemcpyAsync(pc, sel(c, c->pc), N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (v_arr) HIP_TRY(hipMemcpyAsync(v_arr, sel(c, c->v_arr), m * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (pc_arr) HIP_TRY(hipMemcpyAsync(pc_arr, sel(c, c->pc_arr), m * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (nj) HIP_TRY(hipMemcpyAsync(nj, sel(c, c->nj), m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (lj) HIP_TRY(hipMemcpyAsync(lj, sel(c, c->lj), m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (iterator) HIP_TRY(hipMemcpyAsync(iterator, sel(c, c->iterator), m * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LMCMA_HIP_OK;
 }
@@ -1270,7 +1361,7 @@ int lmcma_hip_buffer(lmcma_hip_ctx *c, int which, void **device_ptr, size_t *byt
         case LMCMA_BUF_PERM: p = c->perm; b = (size_t)c->lambda * sizeof(int32_t); break;
         default: return fail(LMCMA_HIP_ERR_ARG, "unknown buffer id");
     }
-    *device_ptr = p;
+    *device_ptr = sel(c, static_cast<char *>(p));
     if (bytes) *bytes = b;
     return LMCMA_HIP_OK;
 }

@@ -1,9 +1,21 @@
 // Device functions shared by the sampling, cost and fused generation kernels.
 #pragma once
 
+#include <type_traits>
+
 #include "device_types.hpp"
 
 namespace lmcma {
+
+// query q's copy of a context buffer (see Batch); null stays null
+template <typename T>
+__device__ __forceinline__ void shift_ptr(T *&p, size_t bytes)
+{
+    // pointer arithmetic, not an integer round trip: the compiler keeps treating p as global memory
+    using Byte = typename std::conditional<std::is_const<T>::value, const char, char>::type;
+    if (p) p = reinterpret_cast<T *>(reinterpret_cast<Byte *>(p) + bytes);
+}
+
 
 // ---- counter-based normals ---------------------------------------------------------
 
@@ -23,6 +35,35 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// sin(2 pi u), cos(2 pi u) for u in [0, 1): the angle in quarter turns n + r, |r| <= 1/2, and the
+// two polynomials of sinpi / cospi on [-1/4, 1/4] turns (degrees 7 and 8; absolute error below
+// 2e-7), exchanged and negated by quadrant.  The library's sincospif adds the handling of huge,
+// infinite and NaN arguments, which cannot occur here.
+__device__ __forceinline__ void sincos_2pi(float u, float &s, float &c)
+{
+    const float t = 4.0f * u;                 // quarter turns, [0, 4)
+    const float n = rintf(t);                 // 0 .. 4
+    const float r = (t - n) * 0.25f;          // turns / 2 ... in [-1/8, 1/8]: angle = 2 pi (n / 4 + r)
+    const float x = 2.0f * r;                 // half turns in [-1/4, 1/4]: sinpi(x), cospi(x)
+    const float x2 = x * x;
+    // sinpi(x) = x (pi + x^2 (-pi^3/6 + x^2 (pi^5/120 + x^2 (-pi^7/5040))))
+    float sp = fmaf(x2, -0.59926452f, 2.55016404f);
+    sp = fmaf(x2, sp, -5.16771278f);
+    sp = fmaf(x2, sp, 3.14159265f);
+    sp *= x;
+    // cospi(x) = 1 + x^2 (-pi^2/2 + x^2 (pi^4/24 + x^2 (-pi^6/720 + x^2 pi^8/40320)))
+    float cp = fmaf(x2, 0.23533063f, -1.33526277f);
+    cp = fmaf(x2, cp, 4.05871213f);
+    cp = fmaf(x2, cp, -4.93480220f);
+    cp = fmaf(x2, cp, 1.0f);
+    const int q = (int)n;                     // quadrant 0..4 (4 = a full turn)
+    const bool swap = (q & 1) != 0;
+    const float ss = swap ? cp : sp, cc = swap ? sp : cp;
+    // quadrant 1: (cos, -sin); 2: (-sin, -cos); 3: (-cos, sin)
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+}
+
 // Four standard normals for element quad `chunk` of (generation, candidate):
 // counter (chunk, candidate, generation, 0), key = seed; two Box-Muller transforms
 // on u = ((r >> 9) + 0.5) 2^-23 in (0,1), which fp32 holds exactly.
@@ -36,11 +77,12 @@ __device__ __forceinline__ float4 philox_normals(uint32_t chunk, uint32_t candid
     const float u2a = ((float)(r[1] >> 9) + 0.5f) * scale;
     const float u1b = ((float)(r[2] >> 9) + 0.5f) * scale;
     const float u2b = ((float)(r[3] >> 9) + 0.5f) * scale;
-    const float ra = sqrtf(-2.0f * logf(u1a));
-    const float rb = sqrtf(-2.0f * logf(u1b));
+    // (v_sqrt_f32: 1 ulp)
+    const float ra = __builtin_amdgcn_sqrtf(-2.0f * logf(u1a));
+    const float rb = __builtin_amdgcn_sqrtf(-2.0f * logf(u1b));
     float sa, ca, sb, cb;
-    sincospif(2.0f * u2a, &sa, &ca);
-    sincospif(2.0f * u2b, &sb, &cb);
+    sincos_2pi(u2a, sa, ca);
+    sincos_2pi(u2b, sb, cb);
     return make_float4(ra * ca, ra * sa, rb * cb, rb * sb);
 }
 
@@ -224,8 +266,57 @@ __device__ __forceinline__ WaypointPart waypoint_prepare(const CostParams &p, co
         acc2 = fmaf(a, a, acc2);
     }
     WaypointPart w;
-    w.len_prev = sqrtf(len_prev2);
-    w.len_next = sqrtf(len_next2);
+    // v_sqrt_f32: 1 ulp, well inside the cost's tolerance; sqrtf is a dozen instructions more
+    w.len_prev = __builtin_amdgcn_sqrtf(len_prev2);
+    w.len_next = __builtin_amdgcn_sqrtf(len_next2);
+    w.acc2 = acc2;
+    w.cell = grid_cell<D>(p, q0);
+    return w;
+}
+
+// The same for a row kept in LDS with its dimensions padded: dimension d occupies
+// prow[d (W + 4) + 2 .. + W), preceded by two copies of start[d] and followed by two of goal[d],
+// so the waypoint's four neighbours are read at fixed offsets with no index clamp and, with the
+// end points as padding (LMCMA_PAD_ENDPOINT), no select.  Same arithmetic as waypoint_prepare.
+template <int D>
+__device__ __forceinline__ WaypointPart waypoint_prepare_padded(const CostParams &p, const float *prow, int k)
+{
+    constexpr float c_far = -1.0f / 12.0f, c_near = 16.0f / 12.0f;
+    const int W = p.W;
+    float r0[D], rm1[D], rp1[D], rm2[D], rp2[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float *r = prow + d * (W + 4) + 2 + k;
+        r0[d] = r[0];
+        rm1[d] = r[-1];
+        rp1[d] = r[1];
+        rm2[d] = r[-2];
+        rp2[d] = r[2];
+    }
+    asm volatile("" ::: "memory");
+    float q0[D];
+    float len_prev2 = 0.f, len_next2 = 0.f, acc2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float v0 = r0[d];
+        const float vm1 = rm1[d], vp1 = rp1[d];
+        float sm1 = vm1, sp1 = vp1, sm2 = rm2[d], sp2 = rp2[d];
+        if (p.pad_zero) {
+            if (k < 1) sm1 = 0.f;
+            if (k < 2) sm2 = 0.f;
+            if (k + 1 >= W) sp1 = 0.f;
+            if (k + 2 >= W) sp2 = 0.f;
+        }
+        q0[d] = v0;
+        const float dm = v0 - vm1, dp = vp1 - v0;
+        len_prev2 = fmaf(dm, dm, len_prev2);
+        len_next2 = fmaf(dp, dp, len_next2);
+        const float a = fmaf(c_far, (sm2 - v0) + (sp2 - v0), c_near * ((sm1 - v0) + (sp1 - v0)));
+        acc2 = fmaf(a, a, acc2);
+    }
+    WaypointPart w;
+    w.len_prev = __builtin_amdgcn_sqrtf(len_prev2);
+    w.len_next = __builtin_amdgcn_sqrtf(len_next2);
     w.acc2 = acc2;
     w.cell = grid_cell<D>(p, q0);
     return w;

@@ -8,6 +8,16 @@
 
 namespace lmcma {
 
+// Several independent optimisers ("queries": restarts or planning queries on one map) in one
+// context.  Every buffer of a context exists once per query, at the same offset inside a
+// per-query block of `stride` bytes, so query q's copy of any of them is the pointer of query 0
+// plus q * stride.  A launch covers all queries: blockIdx.y is the query, and each kernel
+// shifts the pointers of its argument block first.  queries = 1, stride = 0: a plain context.
+struct Batch {
+    int queries;
+    size_t stride;
+};
+
 // Scalars the sampling kernel reads from device memory, so that a captured
 // graph of one generation can be replayed without patching kernel arguments.
 struct SampleScalars {
@@ -31,6 +41,7 @@ struct OptScalars {
     // 1 once sigma < 1e-20 (LMCMA::isBehaviorLearningDone, L/lmcma.cpp:426-429): the update
     // kernels then leave the state as it is, so itr stays at the generation that reached it
     int32_t done;
+    double sigma0;       // step size lmcma_hip_opt_reset returns to
 };
 
 struct CostParams {
@@ -69,6 +80,7 @@ struct GenParams {
     uint32_t first_candidate, key0, key1;
     CostParams cost;          // cost.rows is not used: the rows come from LDS
     CovFactor cov;            // cov.L null: identity
+    Batch batch;              // query q draws from the Philox key (key0 + q, key1)
 };
 
 // Raises a kernel's dynamic LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) when `lds`
@@ -131,6 +143,7 @@ struct SelectArgs {
     // the first part of the update (update_pre_body) may ride along as one more workgroup of
     // the counting launch; SelectResult::pre_done tells whether it did
     const UpdateArgs *pre;
+    Batch batch;                   // counting path only
 };
 struct SelectResult {
     int partial_rows;   // rows of block_partials written (0: recombination not done)
@@ -190,7 +203,7 @@ hipError_t launch_recombine_final(hipStream_t s, const double *block_partials, i
 constexpr int kReducedRowsMax = 32;
 constexpr int kReduceRowsFrom = 192;
 int reduce_rows_out(int rows);
-hipError_t launch_reduce_rows(hipStream_t s, const double *src, int rows, int N, double *dst);
+hipError_t launch_reduce_rows(hipStream_t s, const double *src, int rows, int N, double *dst, Batch batch);
 
 // workgroup size the update uses for m direction vectors of N parameters
 int update_threads(int N, int m);
@@ -216,6 +229,7 @@ struct UpdateArgs {
     int32_t *t, *vec, *iterator; // [m]
     float *xmean_f;             // [ld]
     float *V_f, *B_f;           // [m][ld] in iterator order, B = M^(k-1-t) nj pc
+    Batch batch;
 };
 hipError_t launch_update(hipStream_t s, const UpdateArgs &a);
 // The update in two launches (update_body.hpp): vectors that do not depend on this generation's

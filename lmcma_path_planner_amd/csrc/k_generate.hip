@@ -13,6 +13,10 @@
 // so the row never comes back from HBM.  The direction vectors (V, B) are staged in
 // LDS once per block when they fit, and a bit-packed occupancy grid can be staged
 // beside them; blocks walk several candidate tiles to amortise that staging.
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "device_funcs.hpp"
 
 namespace lmcma {
@@ -32,6 +36,10 @@ constexpr int kLanes = 32;           // lanes per candidate
 template <int J>
 constexpr int kDirectionsPerPass = J == 1 ? 16 : J == 2 ? 8 : 4;
 constexpr int kTile = 256 / kLanes;  // candidates per block pass
+constexpr int kBatchBlocks = 2048;   // workgroups of a launch that covers several queries
+
+// floats of a row in LDS with each of its D dimensions padded by two entries on either side
+__host__ __device__ constexpr int padded_row_floats(int D, int W) { return (D * (W + 4) + 3) & ~3; }
 
 // J = float4 chunks per lane (row stride <= 128 J floats)
 // COV: the normals pass through the factor of a structured covariance first (apply_factor)
@@ -39,13 +47,23 @@ template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV>
 __global__ __launch_bounds__(256) void k_generate(const GenParams g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // query blockIdx.y of a batch: its copies of the context's buffers, its own Philox key.  (Only
+    // the pointers are copied: a modified copy of the whole argument block would live in scratch
+    // memory, because the covariance factor's block table in it is indexed at run time.)
+    const size_t qoff = (size_t)blockIdx.y * g.batch.stride;
+    float *q_rows = g.rows, *q_cost = g.cost.cost, *q_terms = g.cost.terms;
+    const float *q_xmean = g.xmean, *q_V = g.V, *q_B = g.B, *q_lo = g.lo, *q_hi = g.hi;
+    const SampleScalars *q_sc = g.sc;
+    shift_ptr(q_rows, qoff); shift_ptr(q_cost, qoff); shift_ptr(q_terms, qoff); shift_ptr(q_xmean, qoff);
+    shift_ptr(q_V, qoff); shift_ptr(q_B, qoff); shift_ptr(q_lo, qoff); shift_ptr(q_hi, qoff); shift_ptr(q_sc, qoff);
+    const uint32_t q_key0 = g.key0 + blockIdx.y;
     const CostParams &p = g.cost;
     const int ld = g.ld;
     const int nchunks = ld >> 2;
-    const int k = g.sc->k;
-    const float sigma = g.sc->sigma;
-    const float mk = g.sc->mk;
-    const uint32_t generation = g.sc->generation;
+    const int k = q_sc->k;
+    const float sigma = q_sc->sigma;
+    const float mk = q_sc->mk;
+    const uint32_t generation = q_sc->generation;
 
 #ifdef LMCMA_DIAG
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -54,8 +72,12 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
     constexpr int LDP = J * 128;               // LDS stride of a direction vector: reads need no bounds
     constexpr int U = kDirectionsPerPass<J>;   // direction vectors per pass of the sampling loop
     const int mp = (g.m + U - 1) / U * U;      // rows of the LDS copies: whole passes, zero beyond k
-    float *srows = smem;                       // [kTile][ld]
-    float *sV = srows + kTile * ld;            // [mp][LDP] when VB_LDS, zero beyond ld and beyond row k
+    // The tile's rows for the scoring half, every dimension padded with the fixed end points:
+    // dimension d of a row at [d (W + 4) + 2, + W), two copies of start[d] before and of goal[d]
+    // after it (waypoint_prepare_padded)
+    const int LP = padded_row_floats(D, p.W);
+    float *srows = smem;                       // [kTile][LP]
+    float *sV = srows + kTile * LP;            // [mp][LDP] when VB_LDS, zero beyond ld and beyond row k
     float *sB = sV + (VB_LDS ? mp * LDP : 0);  // [mp][LDP] when VB_LDS, likewise
     float *s_z = sB + (VB_LDS ? mp * LDP : 0);  // [16][16 ntiles + 4] when COV
     uint32_t *sbits = reinterpret_cast<uint32_t *>(s_z + (COV ? factor_lds_floats(g.cov.ntiles) : 0));
@@ -70,16 +92,16 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
     for (int j = 0; j < J; ++j) {
         const int chunk = j * kLanes + lane;
         const int cc = chunk < nchunks ? chunk : nchunks - 1;
-        xm[j] = reinterpret_cast<const float4 *>(g.xmean)[cc];
-        l4[j] = reinterpret_cast<const float4 *>(g.lo)[cc];
-        h4[j] = reinterpret_cast<const float4 *>(g.hi)[cc];
+        xm[j] = reinterpret_cast<const float4 *>(q_xmean)[cc];
+        l4[j] = reinterpret_cast<const float4 *>(q_lo)[cc];
+        h4[j] = reinterpret_cast<const float4 *>(q_hi)[cc];
     }
     if (VB_LDS) {
         // All rows, whatever k is: the loads then do not wait for the scalar load of k (rows
         // from k on are stored as zeros: the sampling loop below runs in whole passes).
         const int n4 = mp * (LDP >> 2);
-        const float4 *srcV = reinterpret_cast<const float4 *>(g.V);
-        const float4 *srcB = reinterpret_cast<const float4 *>(g.B);
+        const float4 *srcV = reinterpret_cast<const float4 *>(q_V);
+        const float4 *srcB = reinterpret_cast<const float4 *>(q_B);
         float4 *dstV = reinterpret_cast<float4 *>(sV), *dstB = reinterpret_cast<float4 *>(sB);
         for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * 256) {
             float4 tv[4], tb[4];
@@ -103,6 +125,21 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
             }
         }
     }
+    // where this lane's elements go in a padded row (-1: beyond the row), and the pads themselves
+    int pos[J][4];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = 4 * (j * kLanes + lane) + e;
+            const int d = (D > 1 && n >= p.W ? 1 : 0) + (D > 2 && n >= 2 * p.W ? 1 : 0);  // n / W without a division
+            pos[j][e] = n < D * p.W ? n + 4 * d + 2 : -1;
+        }
+    }
+    if (threadIdx.x < kTile * D * 4) {
+        const int e = threadIdx.x & 3, d = (threadIdx.x >> 2) % D, sl = threadIdx.x / (4 * D);
+        srows[sl * LP + d * (p.W + 4) + (e < 2 ? e : p.W + e)] = e < 2 ? p.start[d] : p.goal[d];
+    }
     const uint32_t *bits;
     if (GRID_LDS) {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.grid);
@@ -112,8 +149,8 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
     } else {
         bits = reinterpret_cast<const uint32_t *>(p.grid);
     }
-    const float *Vp = VB_LDS ? sV : g.V;
-    const float *Bp = VB_LDS ? sB : g.B;
+    const float *Vp = VB_LDS ? sV : q_V;
+    const float *Bp = VB_LDS ? sB : q_B;
 
     const int ntiles = (g.n_local + kTile - 1) / kTile;
 
@@ -128,7 +165,7 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
         for (int j = 0; j < J; ++j) {
             const int chunk = j * kLanes + lane;
             z[j] = (chunk < nchunks) ? philox_normals((uint32_t)chunk, g.first_candidate + (uint32_t)c,
-                                                      generation, g.key0, g.key1)
+                                                      generation, q_key0, g.key1)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         // (the scoring half of the previous tile does not touch the factor's LDS, and two
@@ -229,8 +266,8 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
         }
 
         GEN_STAMP(3);
-        float4 *out = reinterpret_cast<float4 *>(g.rows + (size_t)c * ld);
-        float4 *lrow = reinterpret_cast<float4 *>(srows + slot * ld);
+        float4 *out = reinterpret_cast<float4 *>(q_rows + (size_t)c * ld);
+        float *lrow = srows + slot * LP;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int chunk = j * kLanes + lane;
@@ -241,7 +278,10 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
                 x.y = fminf(fmaxf(fmaf(sigma, acc[j].y, xm[j].y), l4[j].y), h4[j].y);
                 x.z = fminf(fmaxf(fmaf(sigma, acc[j].z, xm[j].z), l4[j].z), h4[j].z);
                 x.w = fminf(fmaxf(fmaf(sigma, acc[j].w, xm[j].w), l4[j].w), h4[j].w);
-                lrow[chunk] = x;
+                if (pos[j][0] >= 0) lrow[pos[j][0]] = x.x;
+                if (pos[j][1] >= 0) lrow[pos[j][1]] = x.y;
+                if (pos[j][2] >= 0) lrow[pos[j][2]] = x.z;
+                if (pos[j][3] >= 0) lrow[pos[j][3]] = x.w;
                 if (live) out[chunk] = x;
             }
         }
@@ -250,14 +290,14 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
 
         // ---- score ---------------------------------------------------------------------
         float j_len = 0.f, j_grid = 0.f, j_smooth = 0.f;
-        const float *row = srows + slot * ld;
+        const float *row = srows + slot * LP;
         // two waypoints per pass: both grid lookups (the only global loads of this half, at
         // data-dependent addresses) are in flight together; the terms are added in waypoint order
         for (int w0 = lane; w0 < p.W; w0 += 2 * kLanes) {
             const int w1 = w0 + kLanes;
             const bool has1 = w1 < p.W;
-            const WaypointPart a = waypoint_prepare<D>(p, row, w0);
-            const WaypointPart b = waypoint_prepare<D>(p, row, has1 ? w1 : w0);
+            const WaypointPart a = waypoint_prepare_padded<D>(p, row, w0);
+            const WaypointPart b = waypoint_prepare_padded<D>(p, row, has1 ? w1 : w0);
             const float ca = grid_value_at(p, bits, a.cell);
             const float cb = grid_value_at(p, bits, b.cell);
             waypoint_finish(p, a, w0, ca, j_len, j_grid, j_smooth);
@@ -268,9 +308,9 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
         j_smooth = group_sum<kLanes>(j_smooth);
         GEN_STAMP(5);
         if (live && lane == 0) {
-            p.cost[cand] = total_cost(p, j_len, j_grid, j_smooth);
-            if (p.terms) {
-                float *t = p.terms + 3 * (size_t)cand;
+            q_cost[cand] = total_cost(p, j_len, j_grid, j_smooth);
+            if (q_terms) {
+                float *t = q_terms + 3 * (size_t)cand;
                 t[0] = j_len; t[1] = j_grid; t[2] = j_smooth;
             }
         }
@@ -291,7 +331,7 @@ hipError_t launch_t(hipStream_t s, const GenParams &g, size_t lds, int blocks)
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_generate<J, D, GRID_LDS, VB_LDS, COV>), lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_generate<J, D, GRID_LDS, VB_LDS, COV>), dim3(blocks), dim3(256), lds, s, g);
+    hipLaunchKernelGGL((k_generate<J, D, GRID_LDS, VB_LDS, COV>), dim3(blocks, g.batch.queries), dim3(256), lds, s, g);
     return hipGetLastError();
 }
 
@@ -299,7 +339,7 @@ template <int J, int D>
 hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds)
 {
     const int ntiles = (g.n_local + kTile - 1) / kTile;
-    const size_t rows_b = (size_t)kTile * g.ld * sizeof(float);
+    const size_t rows_b = (size_t)kTile * padded_row_floats(D, g.cost.W) * sizeof(float);
     constexpr int U = kDirectionsPerPass<J>;
     const size_t vb_b = 2 * (size_t)((g.m + U - 1) / U * U) * (J * 128) * sizeof(float);  // whole passes of padded rows
     const bool cov = g.cov.L != nullptr;
@@ -312,8 +352,15 @@ hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds)
     const size_t lds = rows_b + (vb_lds ? vb_b : 0) + (grid_lds ? grid_b : 0) + cov_b;
     // staging is paid per block: one block per CU when something is staged and there
     // are enough tiles, otherwise one block per tile up to eight blocks per CU
-    const int blocks = (grid_lds || vb_lds) ? (ntiles < 512 ? ntiles : (grid_lds ? 256 : 512))
-                                            : (ntiles < 2048 ? ntiles : 2048);
+    int blocks = (grid_lds || vb_lds) ? (ntiles < 512 ? ntiles : (grid_lds ? 256 : 512))
+                                      : (ntiles < 2048 ? ntiles : 2048);
+    // several queries: the launch has that many times the workgroups, so each query gets fewer, and a
+    // workgroup's staged vectors serve several tiles (about eight workgroups per CU over the launch)
+    if (g.batch.queries > 1) {
+        int per_query = kBatchBlocks / g.batch.queries;
+        if (const char *f = getenv("LMCMA_HIP_BATCH_BLOCKS")) per_query = atoi(f) / g.batch.queries;
+        blocks = std::min(blocks, std::max(per_query, 1));
+    }
     if (cov) {
         if (vb_lds) return launch_t<J, D, false, true, true>(s, g, lds, blocks);
         return launch_t<J, D, false, false, true>(s, g, lds, blocks);
@@ -350,6 +397,7 @@ extern "C" hipError_t lmcma_diag_generate_stamps(unsigned long long *out16)
 hipError_t launch_generate(hipStream_t s, const GenParams &g, int dims, bool grid_lds)
 {
     if (g.n_local <= 0) return hipSuccess;
+    if (g.batch.queries < 1) return hipErrorInvalidValue;
     if (g.ld <= 0 || (g.ld & 3) || g.ld > 512 || g.cost.W < 1 || dims * g.cost.W > g.ld)
         return hipErrorInvalidValue;
     if (grid_lds && (g.cost.grid_type != LMCMA_GRID_BITS || (g.cost.grid_words & 3))) return hipErrorInvalidValue;

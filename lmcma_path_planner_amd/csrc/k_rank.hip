@@ -46,6 +46,7 @@ struct RankArgs {
     // PRE_EMAX > 0: the last workgroup of the grid runs the first part of the update instead
     UpdateArgs pre;
     int pre_threads;
+    Batch batch;
 };
 
 __device__ __forceinline__ uint32_t row16_sum_u32(uint32_t v)
@@ -78,16 +79,23 @@ size_t rank_lds_bytes(int TB, int lambda, int N, int mu, bool psr, bool recombin
 #endif
 
 template <int TB, int PRE_EMAX>
-__global__ __launch_bounds__(TB) void k_rank(const RankArgs r)
+__global__ __launch_bounds__(TB) void k_rank(const RankArgs r_in)
 {
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     if (PRE_EMAX > 0) {
         // The vectors of the direction store that do not depend on this generation's costs are
         // rebuilt here, on a CU the ranking leaves idle, instead of after the ranking.
         if (blockIdx.x == gridDim.x - 1) {
-            update_pre_body<(PRE_EMAX > 0 ? PRE_EMAX : 8)>(r.pre, s_dyn, r.pre_threads);
+            update_pre_body<(PRE_EMAX > 0 ? PRE_EMAX : 8)>(shifted(r_in.pre, blockIdx.y), s_dyn, r_in.pre_threads);
             return;
         }
+    }
+    RankArgs r = r_in;
+    if (r.batch.stride != 0) {
+        const size_t off = (size_t)blockIdx.y * r.batch.stride;  // query blockIdx.y of a batch
+        shift_ptr(r.cost, off); shift_ptr(r.sorted_cost, off); shift_ptr(r.perm, off); shift_ptr(r.opt, off);
+        shift_ptr(r.prev_sorted, off); shift_ptr(r.psr_parts, off); shift_ptr(r.rows, off); shift_ptr(r.weights, off);
+        shift_ptr(r.block_partials, off);
     }
     constexpr int CPB = TB / 16;  // candidates per workgroup
     const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
@@ -528,7 +536,7 @@ hipError_t launch_rank_tp(hipStream_t s, const RankArgs &r, int blocks, size_t l
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_rank<TB, PRE_EMAX>), lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_rank<TB, PRE_EMAX>), dim3(blocks + (PRE_EMAX > 0 ? 1 : 0)), dim3(TB), lds, s, r);
+    hipLaunchKernelGGL((k_rank<TB, PRE_EMAX>), dim3(blocks + (PRE_EMAX > 0 ? 1 : 0), r.batch.queries), dim3(TB), lds, s, r);
     return hipGetLastError();
 }
 
@@ -612,10 +620,14 @@ hipError_t launch_select(hipStream_t s, const SelectArgs &a, SelectResult *res)
     const int lambda = a.lambda;
     if (lambda <= 0) return hipErrorInvalidValue;
 
-    if (!select_by_counting(lambda)) return launch_select_sort(s, a);
+    if (!select_by_counting(lambda)) {
+        if (a.batch.queries > 1) return hipErrorInvalidValue;  // batches are ranked by counting only
+        return launch_select_sort(s, a);
+    }
 
     const OptScalars *opt = (a.prev_sorted && a.psr_accum) ? a.opt : nullptr;
     RankArgs r{};
+    r.batch = a.batch.queries >= 1 ? a.batch : Batch{1, 0};
     r.cost = a.cost_all;
     r.lambda = lambda;
     r.sorted_cost = a.sorted_cost;

@@ -82,10 +82,12 @@ __global__ __launch_bounds__(1024) void k_recombine_final(const double *__restri
 // One workgroup reads freshly written rows at some tens of GB/s, so beyond a hundred rows or so
 // the single workgroup that consumes them is better off with a few dozen rows summed by
 // many workgroups first.
-__global__ __launch_bounds__(256) void k_reduce_rows(const double *__restrict__ src, int rows, int chunk, int N,
-                                                     double *__restrict__ dst)
+__global__ __launch_bounds__(256) void k_reduce_rows(const double *src, int rows, int chunk, int N,
+                                                     double *dst, size_t qstride)
 {
     __shared__ double s_red[1024];  // row_sum_lds_doubles(N <= 512, 256)
+    shift_ptr(src, blockIdx.y * qstride);
+    shift_ptr(dst, blockIdx.y * qstride);
     const int first = blockIdx.x * chunk;
     const int count = rows - first < chunk ? rows - first : chunk;
     row_sums_to_lds(src + (size_t)first * N, count, N, N, 256, s_red);
@@ -107,21 +109,21 @@ __global__ __launch_bounds__(update_block_threads(TB)) void k_update(const Updat
 {
     // all LDS in one dynamic array of doubles
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-    update_body<EMAX, V_LDS>(a, s_dyn, TB, update_row_threads(TB));
+    update_body<EMAX, V_LDS>(shifted(a, blockIdx.y), s_dyn, TB, update_row_threads(TB));
 }
 
 template <int TB, int EMAX>
 __global__ __launch_bounds__(TB) void k_update_pre(const UpdateArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-    update_pre_body<EMAX>(a, s_dyn, TB);
+    update_pre_body<EMAX>(shifted(a, blockIdx.y), s_dyn, TB);
 }
 
 template <int TB, int EMAX>
 __global__ __launch_bounds__(update_block_threads(TB)) void k_update_post(const UpdateArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-    update_post_body<EMAX>(a, s_dyn, TB, update_row_threads(TB));
+    update_post_body<EMAX>(shifted(a, blockIdx.y), s_dyn, TB, update_row_threads(TB));
 }
 
 }  // namespace
@@ -188,11 +190,12 @@ int reduce_rows_out(int rows)
     return (rows + chunk - 1) / chunk;
 }
 
-hipError_t launch_reduce_rows(hipStream_t s, const double *src, int rows, int N, double *dst)
+hipError_t launch_reduce_rows(hipStream_t s, const double *src, int rows, int N, double *dst, Batch batch)
 {
-    if (rows < 1 || N < 1 || N > 512) return hipErrorInvalidValue;
+    if (rows < 1 || N < 1 || N > 512 || batch.queries < 1) return hipErrorInvalidValue;
     const int chunk = (rows + kReducedRowsMax - 1) / kReducedRowsMax;
-    hipLaunchKernelGGL(k_reduce_rows, dim3(reduce_rows_out(rows)), dim3(256), 0, s, src, rows, chunk, N, dst);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(reduce_rows_out(rows), batch.queries), dim3(256), 0, s, src, rows, chunk, N,
+                       dst, batch.stride);
     return hipGetLastError();
 }
 
@@ -214,7 +217,7 @@ static hipError_t launch_update_t(hipStream_t s, const UpdateArgs &a)
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_update<TB, EMAX, V_LDS>), lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_update<TB, EMAX, V_LDS>), dim3(1), dim3(update_block_threads(TB)), lds, s, a);
+    hipLaunchKernelGGL((k_update<TB, EMAX, V_LDS>), dim3(1, a.batch.queries), dim3(update_block_threads(TB)), lds, s, a);
     return hipGetLastError();
 }
 
@@ -226,7 +229,7 @@ static hipError_t launch_pre_t(hipStream_t s, const UpdateArgs &a)
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_update_pre<TB, EMAX>), lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_update_pre<TB, EMAX>), dim3(1), dim3(TB), lds, s, a);
+    hipLaunchKernelGGL((k_update_pre<TB, EMAX>), dim3(1, a.batch.queries), dim3(TB), lds, s, a);
     return hipGetLastError();
 }
 
@@ -238,7 +241,7 @@ static hipError_t launch_post_t(hipStream_t s, const UpdateArgs &a)
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_update_post<TB, EMAX>), lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_update_post<TB, EMAX>), dim3(1), dim3(update_block_threads(TB)), lds, s, a);
+    hipLaunchKernelGGL((k_update_post<TB, EMAX>), dim3(1, a.batch.queries), dim3(update_block_threads(TB)), lds, s, a);
     return hipGetLastError();
 }
 
@@ -254,7 +257,7 @@ static hipError_t launch_post_t(hipStream_t s, const UpdateArgs &a)
 
 hipError_t launch_update_pre(hipStream_t s, const UpdateArgs &a)
 {
-    if (!update_is_split(a.N, a.m)) return hipErrorInvalidValue;
+    if (!update_is_split(a.N, a.m) || a.batch.queries < 1) return hipErrorInvalidValue;
     const int threads = threads_for_vectors(a.m), emax = update_emax(a.N);
     if (threads == 256) LMCMA_UPD_SPLIT(launch_pre_t, 256);
     if (threads == 512) LMCMA_UPD_SPLIT(launch_pre_t, 512);
@@ -263,7 +266,7 @@ hipError_t launch_update_pre(hipStream_t s, const UpdateArgs &a)
 
 hipError_t launch_update_post(hipStream_t s, const UpdateArgs &a)
 {
-    if (!update_is_split(a.N, a.m) || a.n_partials < 1) return hipErrorInvalidValue;
+    if (!update_is_split(a.N, a.m) || a.n_partials < 1 || a.batch.queries < 1) return hipErrorInvalidValue;
     const int threads = threads_for_vectors(a.m), emax = update_emax(a.N);
     if (threads == 256) LMCMA_UPD_SPLIT(launch_post_t, 256);
     if (threads == 512) LMCMA_UPD_SPLIT(launch_post_t, 512);
@@ -273,7 +276,7 @@ hipError_t launch_update_post(hipStream_t s, const UpdateArgs &a)
 
 hipError_t launch_update(hipStream_t s, const UpdateArgs &a)
 {
-    if (a.m < 1 || a.m > LMCMA_HIP_MAX_VECTORS || a.N < 1 || a.N > 512 || a.n_partials < 1)
+    if (a.m < 1 || a.m > LMCMA_HIP_MAX_VECTORS || a.N < 1 || a.N > 512 || a.n_partials < 1 || a.batch.queries < 1)
         return hipErrorInvalidValue;
     const int threads = threads_for_vectors(a.m);
     const int emax = update_emax(a.N);

@@ -9,6 +9,20 @@
 
 namespace lmcma {
 
+// the argument block of query q (Batch): every context buffer moves by q * stride bytes
+__device__ __forceinline__ UpdateArgs shifted(const UpdateArgs &in, int q)
+{
+    UpdateArgs a = in;
+    const size_t off = (size_t)q * in.batch.stride;
+    if (off == 0) return a;
+    shift_ptr(a.opt, off); shift_ptr(a.sc, off); shift_ptr(a.partials, off); shift_ptr(a.sorted_cost, off);
+    shift_ptr(a.psr_accum, off); shift_ptr(a.psr_parts, off); shift_ptr(a.xmean, off); shift_ptr(a.pc, off);
+    shift_ptr(a.pc_arr, off); shift_ptr(a.v_arr, off); shift_ptr(a.nj, off); shift_ptr(a.lj, off);
+    shift_ptr(a.t, off); shift_ptr(a.vec, off); shift_ptr(a.iterator, off);
+    shift_ptr(a.xmean_f, off); shift_ptr(a.V_f, off); shift_ptr(a.B_f, off);
+    return a;
+}
+
 // ---- rows of doubles added in a fixed order by one workgroup ------------------------
 // Thread (r, n) adds rows r, r + rg, r + 2 rg, ... of column n (rg row groups of cw
 // threads each); the rg partial sums of a column are then added in group order.  The

@@ -32,7 +32,7 @@ class HipContext:
     def __init__(self, n_params, lambda_total, m, dims=0, waypoints=0, lambda_local=None,
                  first_candidate=0, mu=None, z_source=Z_PHILOX, cost_source=None, pad_mode=PAD_ENDPOINT,
                  seed=42, w_len=1.0, w_grid=1000.0, w_smooth=1.0, start=(0, 0, 0), goal=(0, 0, 0),
-                 device=0, stream=None):
+                 device=0, stream=None, queries=1):
         self.lib = _lib.load()
         cfg = HipConfig()
         cfg.struct_size = ctypes.sizeof(HipConfig)
@@ -58,6 +58,8 @@ class HipContext:
             cfg.start[d] = float(s3[d])
             cfg.goal[d] = float(g3[d])
         cfg.stream = stream
+        cfg.queries = queries
+        self.queries = queries
         self.cfg = cfg
         self.N = n_params
         self.lam = lambda_total
@@ -185,6 +187,16 @@ class HipContext:
     def opt_init(self, xmean0, sigma0):
         xmean0 = _f64(xmean0)
         check_hip(self.lib.lmcma_hip_opt_init(self._h, _dp(xmean0), float(sigma0)), "lmcma_hip_opt_init")
+
+    def opt_set_query(self, query, xmean0, sigma0):
+        """Query `query` of a context with several queries starts from its own mean and step size."""
+        xmean0 = _f64(xmean0)
+        check_hip(self.lib.lmcma_hip_opt_set_query(self._h, int(query), _dp(xmean0), float(sigma0)),
+                  "lmcma_hip_opt_set_query")
+
+    def query_select(self, query):
+        """The readers (rows, costs, terms, opt_get, opt_vectors, buffer) address this query from now on."""
+        check_hip(self.lib.lmcma_hip_query_select(self._h, int(query)), "lmcma_hip_query_select")
 
     def opt_reset(self):
         check_hip(self.lib.lmcma_hip_opt_reset(self._h), "lmcma_hip_opt_reset")
