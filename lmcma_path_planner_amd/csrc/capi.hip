@@ -138,6 +138,11 @@ struct lmcma_hip_ctx {
     // costs in candidate order, the local ranking's permutation, and the keys of this / the last
     // generation's own sorted list
     bool merge_protocol = false;
+    // A whole population in one context above one counting tile: ranked in tiles of tile_len keys
+    // (each among itself, ascending lists in `lists`), the tiles then merged like the lists of
+    // shards; local_perm / key_buf cover all tiles.  0: not used.
+    int tile_len = 0;
+    float *lists = nullptr;
     float *cost_raw = nullptr;
     int32_t *local_perm = nullptr;
     uint32_t *key_buf[2] = {nullptr, nullptr};
@@ -387,6 +392,45 @@ int do_select(lmcma_hip_ctx *c, bool with_recombine, int *rows_out, bool with_pr
     // the two sorted-cost buffers alternate: this generation's list is written beside last one's
     c->parity ^= 1;
     c->sorted_cost = c->sorted_buf[c->parity];
+    if (c->tile_len > 0 && with_recombine && c->have_weights && c->opt_ready) {
+        // tiles ranked among themselves (the first part of the update may ride along), then merged:
+        // global ranks, the success-rule count and the elite rows, as for the lists of shards
+        SelectArgs t{};
+        t.cost_all = c->cost_all;
+        t.lambda = c->lambda;
+        t.keys_ws = c->keys;
+        t.sorted_cost = c->lists;
+        t.perm = c->local_perm;
+        t.tile_len = c->tile_len;
+        t.batch = batch_of(c);
+        const UpdateArgs pre = update_args(c, nullptr, 0, false);
+        t.pre = (with_pre && !c->pre_done) ? &pre : nullptr;
+        SelectResult tres{};
+        HIP_TRY(launch_select(c->stream, t, &tres));
+        if (tres.pre_done) c->pre_done = true;
+        MergeArgs a{};
+        a.lists = c->lists;
+        a.owners = c->lambda / c->tile_len;
+        a.lambda = c->lambda; a.n_local = c->tile_len; a.first_candidate = 0;
+        a.local_perm = c->local_perm;
+        a.sorted_cost = c->sorted_cost;
+        a.perm = c->perm;
+        a.opt = c->opt;
+        a.prev_own = c->key_buf[c->parity ^ 1];
+        a.own_out = c->key_buf[c->parity];
+        a.psr_parts = reinterpret_cast<uint32_t *>(c->keys);
+        a.best_out = c->best;
+        a.rows = c->rows; a.ld = c->ld; a.N = c->N;
+        a.weights = c->weights; a.mu = c->mu;
+        a.block_partials = c->block_partials;
+        int rows = 0;
+        HIP_TRY(launch_rank_merge(c->stream, a, &rows));
+        c->psr_parts_n = rows;
+        c->ranked_local_only = false;
+        if (rows_out) *rows_out = rows;
+        c->selected = true;
+        return LMCMA_HIP_OK;
+    }
     RecombineArgs rc{c->rows, c->ld, c->N, c->first, c->nloc, c->weights, c->mu, c->block_partials};
     const bool recombine = with_recombine && c->have_weights && select_by_counting(c->lambda);
     SelectArgs a{};
@@ -632,6 +676,13 @@ int lmcma_hip_create(const lmcma_hip_config *cfg, lmcma_hip_ctx **out)
         ar.add(&c->local_perm, nloc);
         ar.add(&c->key_buf[0], nloc);
         ar.add(&c->key_buf[1], nloc);
+    }
+    if (c->nloc == c->lambda && c->Q == 1) c->tile_len = rank_tile_len(c->lambda);
+    if (c->tile_len > 0) {
+        ar.add(&c->lists, lam + 4);
+        ar.add(&c->local_perm, lam);
+        ar.add(&c->key_buf[0], lam);
+        ar.add(&c->key_buf[1], lam);
     }
     ar.add(&c->block_partials,
            (size_t)std::max(recombine_num_blocks(c->mu), select_max_partial_rows(c->first, c->nloc)) * N);

@@ -144,6 +144,10 @@ struct SelectArgs {
     // the counting launch; SelectResult::pre_done tells whether it did
     const UpdateArgs *pre;
     Batch batch;                   // counting path only
+    // counting path: > 0 = the population is ranked in tiles of this many keys, each tile among
+    // itself (sorted_cost and perm then hold one ascending list and one tile-local permutation per
+    // tile, back to back); lambda must be a multiple of it.  launch_rank_merge combines the tiles.
+    int tile_len;
 };
 struct SelectResult {
     int partial_rows;   // rows of block_partials written (0: recombination not done)
@@ -160,6 +164,10 @@ hipError_t launch_select_sort(hipStream_t s, const SelectArgs &a);
 // cost.  sorted_cost / perm receive the local candidates' entries only.
 struct MergeArgs {
     const float *lists;
+    // owners = 1: the caller owns list first_candidate / n_local (a shard of a population);
+    // owners = lambda / n_local: it owns all of them (one context that ranked its population in
+    // tiles): local_perm, prev_own and own_out then cover all lists, rows the whole population
+    int owners;
     int lambda, n_local, first_candidate;
     const int32_t *local_perm;    // [n_local] local candidate at local position p (the local ranking's perm)
     float *sorted_cost;
@@ -176,6 +184,8 @@ struct MergeArgs {
     double *block_partials;
 };
 bool rank_merge_possible(int lambda, int n_local, int first_candidate);
+// tile length for ranking a whole population in one context by tiles + merge, 0: not this way
+int rank_tile_len(int lambda);
 hipError_t launch_rank_merge(hipStream_t s, const MergeArgs &a, int *rows_out);
 
 constexpr int kRecombineRanksPerBlock = 32;

@@ -47,6 +47,7 @@ struct RankArgs {
     UpdateArgs pre;
     int pre_threads;
     Batch batch;
+    int tile_len;                // > 0: every tile of this many keys is ranked among itself
 };
 
 __device__ __forceinline__ uint32_t row16_sum_u32(uint32_t v)
@@ -97,6 +98,17 @@ __global__ __launch_bounds__(TB) void k_rank(const RankArgs r_in)
         shift_ptr(r.prev_sorted, off); shift_ptr(r.psr_parts, off); shift_ptr(r.rows, off); shift_ptr(r.weights, off);
         shift_ptr(r.block_partials, off);
     }
+    int bx = blockIdx.x;
+    if (r.tile_len > 0) {
+        // tiles: this workgroup's tile is a population of its own, its list and its (tile-local)
+        // permutation go to the tile's stretch of the outputs
+        const int bpt = r.tile_len / (TB / 16), tile = bx / bpt;
+        bx -= tile * bpt;
+        r.cost += (size_t)tile * r.tile_len;
+        r.sorted_cost += (size_t)tile * r.tile_len;
+        r.perm += (size_t)tile * r.tile_len;
+        r.lambda = r.tile_len;
+    }
     constexpr int CPB = TB / 16;  // candidates per workgroup
     const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
     const int lambda = r.lambda, N = r.N;
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(TB) void k_rank(const RankArgs r_in)
     uint4 *kdst = reinterpret_cast<uint4 *>(s_key);
     float4 *pdst = reinterpret_cast<float4 *>(s_prev);
     double2 *wdst = reinterpret_cast<double2 *>(s_weights);
-    const int c0 = blockIdx.x * CPB;
+    const int c0 = bx * CPB;
     const RowSumPlan pl = row_sum_plan(N, TB);
     const int ch = (CPB + pl.rg - 1) / pl.rg;  // candidates per row group
     const int rgi = tid / pl.cw, n0 = tid % pl.cw;
@@ -359,6 +371,7 @@ struct RankMergeArgs {
     const double *weights;
     int mu;
     double *block_partials;       // [gridDim.x][N]
+    int owners;                   // 1, or G: this launch ranks the elements of every list (see MergeArgs)
 };
 
 constexpr int kMergeChunk = 32768;  // keys in LDS at a time (128 KiB)
@@ -389,6 +402,11 @@ __global__ __launch_bounds__(TB) void k_rank_merge(const RankMergeArgs r)
     const int lambda = r.lambda, N = r.N, nl = r.n_local;
     const int G = lambda / nl;
     const bool psr = r.opt != nullptr && r.opt->itr > 0;
+    // the list this workgroup's elements belong to, and its workgroup index within that list
+    const int bpl = (nl + CPB - 1) / CPB;
+    const int me = r.owners > 1 ? (int)blockIdx.x / bpl : r.me;
+    const int bx = r.owners > 1 ? (int)blockIdx.x % bpl : (int)blockIdx.x;
+    const size_t own0 = r.owners > 1 ? (size_t)me * nl : 0;  // where list `me` starts in the per-owner arrays
 
     double *s_part = s_dyn;                               // [rg][N]
     double *s_w = s_part + (((TB > N ? TB : N) + 1) & ~1);  // [CPB]
@@ -400,12 +418,12 @@ __global__ __launch_bounds__(TB) void k_rank_merge(const RankMergeArgs r)
     unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
 #endif
     RANK_STAMP(0);
-    const int p = blockIdx.x * CPB + grp;                 // local position of this group's element
+    const int p = bx * CPB + grp;                         // local position of this group's element
     const bool live = p < nl;
     const int pc = live ? p : nl - 1;
-    const uint32_t mine = order_bits(r.lists[(size_t)r.me * nl + pc]);
-    const uint32_t yprev = psr ? r.prev_own[pc] : 0u;
-    const int cand = r.local_perm[pc];
+    const uint32_t mine = order_bits(r.lists[(size_t)me * nl + pc]);
+    const uint32_t yprev = psr ? r.prev_own[own0 + pc] : 0u;
+    const int cand = r.local_perm[own0 + pc];
 
     const int lists_per_chunk = kMergeChunk / nl > 0 ? kMergeChunk / nl : 1;  // n_local <= kMergeChunk
     int rank = lane == 0 ? pc : 0, at_or_below_prev = 0;  // summed over the group's lanes after the searches
@@ -445,7 +463,7 @@ __global__ __launch_bounds__(TB) void k_rank_merge(const RankMergeArgs r)
                 const int gl = prev ? j - ng : j, g = g0 + gl;
                 const uint32_t *s = s_key + (size_t)gl * nl;
                 if (prev) at_or_below_prev += count_below(s, nl, yprev, true);
-                else if (g != r.me) rank += count_below(s, nl, mine, g < r.me);
+                else if (g != me) rank += count_below(s, nl, mine, g < me);
             }
         }
     }
@@ -484,7 +502,7 @@ __global__ __launch_bounds__(TB) void k_rank_merge(const RankMergeArgs r)
                     const int c = rgi * ch + u0 + u;
                     const bool in = u0 + u < ch && c < CPB;
                     w[u] = in ? s_w[c] : 0.0;
-                    x[u] = r.rows[(size_t)s_cand[in ? c : 0] * r.ld + n];
+                    x[u] = r.rows[(own0 + s_cand[in ? c : 0]) * r.ld + n];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
@@ -500,8 +518,8 @@ __global__ __launch_bounds__(TB) void k_rank_merge(const RankMergeArgs r)
     }
     if (lane == 0 && live) {
         r.sorted_cost[rank] = value;
-        r.perm[rank] = r.me * nl + cand;
-        r.own_out[p] = mine;  // this context's list, for the next generation's success rule
+        r.perm[rank] = me * nl + cand;
+        r.own_out[own0 + p] = mine;  // the owner's list, for the next generation's success rule
     }
     if (tid == 0) {
         r.psr_parts[blockIdx.x] = below_total;
@@ -585,6 +603,17 @@ int select_max_partial_rows(int first_candidate, int n_local)
     return (first_candidate + n_local + cpb - 1) / cpb - first_candidate / cpb;
 }
 
+int rank_tile_len(int lambda)
+{
+    // above one tile of the counting rank and up to what the merge holds in LDS at once; equal tiles
+    // that are whole rounds of the counting kernel
+    // (up to two tiles the one-launch counting rank is faster: 11.8 us against 6.6 + 9.2 us at 8192)
+    if (lambda <= 2 * kSortTile || lambda > kMergeChunk || getenv("LMCMA_HIP_NO_TILED_RANK") != nullptr) return 0;
+    const int tiles = (lambda + kSortTile - 1) / kSortTile;
+    if (lambda % tiles != 0 || (lambda / tiles) % 256 != 0) return 0;
+    return lambda / tiles;
+}
+
 bool rank_merge_possible(int lambda, int n_local, int first_candidate)
 {
     return n_local < lambda && n_local % 64 == 0 && lambda % n_local == 0 && first_candidate % n_local == 0 &&
@@ -593,7 +622,8 @@ bool rank_merge_possible(int lambda, int n_local, int first_candidate)
 
 hipError_t launch_rank_merge(hipStream_t s, const MergeArgs &a, int *rows_out)
 {
-    if (!rank_merge_possible(a.lambda, a.n_local, a.first_candidate)) return hipErrorInvalidValue;
+    if (!rank_merge_possible(a.lambda, a.n_local, a.first_candidate) && rank_tile_len(a.lambda) != a.n_local)
+        return hipErrorInvalidValue;
     RankMergeArgs r{};
     r.lists = a.lists;
     r.lambda = a.lambda; r.n_local = a.n_local; r.me = a.first_candidate / a.n_local;
@@ -608,7 +638,9 @@ hipError_t launch_rank_merge(hipStream_t s, const MergeArgs &a, int *rows_out)
     r.rows = a.rows; r.ld = a.ld; r.N = a.N;
     r.weights = a.weights; r.mu = a.mu;
     r.block_partials = a.block_partials;
-    const int blocks = (a.n_local + 31) / 32;
+    r.owners = a.owners > 1 ? a.owners : 1;
+    if (r.owners > 1 && (r.owners != a.lambda / a.n_local || a.first_candidate != 0)) return hipErrorInvalidValue;
+    const int blocks = r.owners * ((a.n_local + 31) / 32);
     if (rows_out) *rows_out = blocks;
     return launch_rank_merge_t<512>(s, r, blocks);
 }
@@ -620,7 +652,10 @@ hipError_t launch_select(hipStream_t s, const SelectArgs &a, SelectResult *res)
     const int lambda = a.lambda;
     if (lambda <= 0) return hipErrorInvalidValue;
 
-    if (!select_by_counting(lambda)) {
+    if (a.tile_len > 0) {
+        if (a.tile_len > kRankCountMax || lambda % a.tile_len != 0 || a.rc != nullptr || a.batch.queries > 1)
+            return hipErrorInvalidValue;
+    } else if (!select_by_counting(lambda)) {
         if (a.batch.queries > 1) return hipErrorInvalidValue;  // batches are ranked by counting only
         return launch_select_sort(s, a);
     }
@@ -628,6 +663,7 @@ hipError_t launch_select(hipStream_t s, const SelectArgs &a, SelectResult *res)
     const OptScalars *opt = (a.prev_sorted && a.psr_accum) ? a.opt : nullptr;
     RankArgs r{};
     r.batch = a.batch.queries >= 1 ? a.batch : Batch{1, 0};
+    r.tile_len = a.tile_len;
     r.cost = a.cost_all;
     r.lambda = lambda;
     r.sorted_cost = a.sorted_cost;
@@ -638,7 +674,8 @@ hipError_t launch_select(hipStream_t s, const SelectArgs &a, SelectResult *res)
     const RecombineArgs *rc = a.rc;
     r.ld = 4;
     r.N = 4;
-    const int cpb = select_candidates_per_block(lambda);
+    const int keys = a.tile_len > 0 ? a.tile_len : lambda;  // keys a workgroup stages and counts over
+    const int cpb = select_candidates_per_block(keys);
     const int TB = cpb * 16;
     const int blocks = (lambda + cpb - 1) / cpb;
     int rows = 0;
@@ -651,9 +688,9 @@ hipError_t launch_select(hipStream_t s, const SelectArgs &a, SelectResult *res)
         rows = (rc->first_candidate + rc->n_local + cpb - 1) / cpb - r.first_block;
     }
     const bool psr = opt != nullptr;
-    size_t lds = rank_lds_bytes(TB, lambda, r.N, r.mu, psr, rc != nullptr, true);
+    size_t lds = rank_lds_bytes(TB, keys, r.N, r.mu, psr, rc != nullptr, true);
     r.weights_in_lds = rc && lds <= 150 * 1024;
-    if (!r.weights_in_lds) lds = rank_lds_bytes(TB, lambda, r.N, r.mu, psr, rc != nullptr, false);
+    if (!r.weights_in_lds) lds = rank_lds_bytes(TB, keys, r.N, r.mu, psr, rc != nullptr, false);
     // The first part of the update as one more workgroup: when the ranking leaves CUs idle
     // (at most one workgroup per CU) and its workgroup is large enough for the vectors.
     int pre_emax = 0;

@@ -894,6 +894,66 @@ def test_merged_ranks_of_shards_equal_the_stable_sort_of_the_whole_population(hi
         c.close()
 
 
+@pytest.mark.parametrize("lam,mode", [(8192, "random"), (12288, "random"), (12288, "ties"),
+                                      (16384, "random"), (16384, "ties"), (20480, "random"), (32768, "random")])
+def test_tiled_rank_of_one_context_equals_the_stable_sort(hip, monkeypatch, lam, mode):
+    """A whole population above 8192 candidates in one context is ranked in tiles of at most 4096
+    (each among itself, by counting) whose ascending lists are then merged.  The permutation and
+    the sorted costs must be those of a stable sort of all costs ("ties": degenerate bounds make
+    every cost equal, so the order is the candidate order), and the state must follow a context
+    that ranks the whole population at once (success-rule count, lowest cost: exactly; the mean:
+    another order of the same fp64 sum)."""
+    import torch
+    from lmcma_path_planner_amd import dist as shard_mod
+    from lmcma_path_planner_amd import grids
+    prob = grids.benchmark_problem(2)
+    dev = torch.device("cuda", 0)
+    lo, hi = (prob.x0, prob.x0) if mode == "ties" else (prob.lo, prob.hi)
+
+    def make():
+        c = hip.HipContext(prob.N, lam, 8, dims=2, waypoints=prob.W, start=prob.start, goal=prob.goal, seed=3)
+        c.set_grid(prob.occ)
+        c.set_bounds(lo, hi)
+        c.opt_init(prob.x0, prob.sigma0)
+        return c
+
+    tiled = make()
+    monkeypatch.setenv("LMCMA_HIP_NO_TILED_RANK", "1")
+    whole = make()
+    monkeypatch.delenv("LMCMA_HIP_NO_TILED_RANK")
+    for gen in range(4):
+        for c in (tiled, whole):
+            c.phase_local()
+        raw = tiled.costs().astype(np.float32)
+        np.testing.assert_array_equal(raw, whole.costs().astype(np.float32))
+        for c in (tiled, whole):
+            c.phase_rank()
+            c.synchronize()
+        order = _reference_order(raw)
+        for c in (tiled, whole):
+            perm = shard_mod.alias_tensor(c, hip.BUF_PERM, torch.int32, dev).cpu().numpy()
+            sc = shard_mod.alias_tensor(c, hip.BUF_SORTED_COST, torch.float32, dev).cpu().numpy()
+            np.testing.assert_array_equal(perm, order)
+            np.testing.assert_array_equal(sc, raw[order])
+        for c in (tiled, whole):
+            c.phase_update(0)
+        a, b = tiled.opt_get(), whole.opt_get()
+        assert a["sigma"] == b["sigma"] and a["s"] == b["s"] and a["best_f"] == b["best_f"] <= float(raw.min())
+        np.testing.assert_allclose(a["xmean"], b["xmean"], rtol=1e-12, atol=1e-12)
+        if mode == "ties":
+            assert np.all(raw == raw[0])
+    # the replayed loop takes the same path
+    tiled.opt_reset()
+    whole.opt_reset()
+    tiled.run(11)
+    whole.run(11)
+    a, b = tiled.opt_get(), whole.opt_get()
+    assert a["itr"] == b["itr"] == 11
+    np.testing.assert_allclose(a["xmean"], b["xmean"], rtol=1e-9, atol=1e-9)
+    tiled.close()
+    whole.close()
+
+
 def test_sharded_generation_over_two_processes():
     """dist.sharded_generation as bench.py --gpus 2 runs it, two ranks on this one GPU (gloo: RCCL
     refuses two ranks on one device), against the unsharded population."""
