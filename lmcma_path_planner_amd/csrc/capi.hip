@@ -339,6 +339,8 @@ int do_evaluate(lmcma_hip_ctx *c)
     return LMCMA_HIP_OK;
 }
 
+UpdateArgs update_args(const lmcma_hip_ctx *c, const double *partials, int n_partials, bool rows_with_scalars);
+
 // sample + score in one launch (device Philox stream only)
 int do_generate(lmcma_hip_ctx *c)
 {
@@ -354,7 +356,11 @@ int do_generate(lmcma_hip_ctx *c)
     g.cost = cost_params(c, c->rows, c->nloc, local_costs(c), c->terms);
     if (c->have_cov) g.cov = c->cov;
     g.batch = batch_of(c);
-    HIP_TRY(launch_generate(c->stream, g, c->D, c->grid_lds));
+    // the first part of this generation's update rides along when it is too long for the ranking launch
+    const UpdateArgs pre = update_args(c, nullptr, 0, false);
+    bool pre_done = false;
+    HIP_TRY(launch_generate(c->stream, g, c->D, c->grid_lds, (c->opt_ready && !c->pre_done) ? &pre : nullptr, &pre_done));
+    if (pre_done) c->pre_done = true;
     c->sampled = true;
     return LMCMA_HIP_OK;
 }
@@ -508,11 +514,18 @@ int do_update(lmcma_hip_ctx *c, const double *partials, int n_partials, bool row
     Timed tm(c, LMCMA_K_UPDATE);
     const UpdateArgs a = update_args(c, partials, n_partials, rows_with_scalars);
     if (update_is_split(a.N, a.m)) {
-        // the part that does not depend on this generation's costs, unless a ranking launch carried it
-        if (!c->pre_done) HIP_TRY(launch_update_pre(c->stream, a));
-        c->pre_done = false;
-        HIP_TRY(launch_update_post(c->stream, a));
-        return LMCMA_HIP_OK;
+        // The part that does not depend on this generation's costs has run with the sampling or the
+        // ranking launch.  If it has not: a short one (up to 16 vectors) runs here, a long one does
+        // not pay on its own, and the single kernel below does the whole update.
+        if (!c->pre_done && update_pre_rides_with_ranking(a.m)) {
+            HIP_TRY(launch_update_pre(c->stream, a));
+            c->pre_done = true;
+        }
+        if (c->pre_done) {
+            c->pre_done = false;
+            HIP_TRY(launch_update_post(c->stream, a));
+            return LMCMA_HIP_OK;
+        }
     }
     HIP_TRY(launch_update(c->stream, a));
     return LMCMA_HIP_OK;

@@ -89,7 +89,11 @@ struct GenParams {
 hipError_t ensure_dynamic_lds(const void *kernel, size_t lds);
 
 // ---- launchers (each in the .hip file that defines its kernels) -------------
-hipError_t launch_generate(hipStream_t s, const GenParams &g, int dims, bool lds_grid);
+struct UpdateArgs;
+// pre: the argument block of this generation's update when its first part may ride along as one
+// more workgroup of the launch (*pre_done tells whether it did); null: never
+hipError_t launch_generate(hipStream_t s, const GenParams &g, int dims, bool lds_grid, const UpdateArgs *pre = nullptr,
+                           bool *pre_done = nullptr);
 
 // cov: null for the identity
 hipError_t launch_sample(hipStream_t s, float *rows, const float *zbuf, const float *xmean,
@@ -245,6 +249,9 @@ hipError_t launch_update(hipStream_t s, const UpdateArgs &a);
 // The update in two launches (update_body.hpp): vectors that do not depend on this generation's
 // costs, then the rest.  update_is_split: the sizes the two-part kernels cover.
 bool update_is_split(int N, int m);
+// the first part is short enough to run as an extra workgroup of the ranking launch; otherwise it
+// gets a stream of its own beside the sampling and ranking launches
+bool update_pre_rides_with_ranking(int m);
 int update_pre_threads(int m);  // threads of the first part that do vector work
 hipError_t launch_update_pre(hipStream_t s, const UpdateArgs &a);
 hipError_t launch_update_post(hipStream_t s, const UpdateArgs &a);

@@ -17,7 +17,7 @@
 
 #include <algorithm>
 
-#include "device_funcs.hpp"
+#include "update_body.hpp"
 
 namespace lmcma {
 
@@ -41,12 +41,39 @@ constexpr int kBatchBlocks = 2048;   // workgroups of a launch that covers sever
 // floats of a row in LDS with each of its D dimensions padded by two entries on either side
 __host__ __device__ constexpr int padded_row_floats(int D, int W) { return (D * (W + 4) + 3) & ~3; }
 
+// Register tile of the update's first part when it rides in a launch whose rows have J * 128
+// floats at most; 0: it does not ride.  Rows of more than 256 parameters do not: with 20
+// coordinates per lane the chain of steps, slowed by the sampling workgroups around it, outlasts
+// the sampling by more than the shorter second part gains (lambda = 16384, N = 288, m = 32:
+// 119 against 114 us per generation).
+__host__ __device__ constexpr int pre_emax_for(int J, int N)
+{
+    return J == 1 ? 8 : J == 2 ? (N <= 192 ? 12 : 16) : 0;
+}
+
 // J = float4 chunks per lane (row stride <= 128 J floats)
 // COV: the normals pass through the factor of a structured covariance first (apply_factor)
-template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV>
-__global__ __launch_bounds__(256) void k_generate(const GenParams g)
+// PRE: workgroup 0 of the launch does not sample: it runs the first part of this generation's
+// update (update_pre_body2: the direction vectors that need nothing of this generation's costs,
+// L/lmcma.cpp:375-390 for all but the newest), which reads and writes nothing the sampling or
+// ranking kernels touch and is too long to ride in the ranking launch when there are more than
+// 16 vectors.  The other workgroups are numbered from 1.
+template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV, bool PRE>
+__global__ __launch_bounds__(256) void k_generate(const GenParams g, const UpdateArgs pre)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (PRE && blockIdx.x == 0) {
+        // This workgroup is a chain of dependent steps that shares its CU with sampling workgroups:
+        // its waves get the instruction issue ahead of theirs.
+        __builtin_amdgcn_s_setprio(3);
+        double *s_dyn = reinterpret_cast<double *>(smem);
+        const UpdateArgs a = shifted(pre, blockIdx.y);
+        if (J == 1) update_pre_body2<8>(a, s_dyn);
+        else if (J == 2 && a.N <= 192) update_pre_body2<12>(a, s_dyn);
+        else if (J == 2) update_pre_body2<16>(a, s_dyn);
+        return;
+    }
+    const int block = (int)blockIdx.x - (PRE ? 1 : 0), nblocks = (int)gridDim.x - (PRE ? 1 : 0);
     // query blockIdx.y of a batch: its copies of the context's buffers, its own Philox key.  (Only
     // the pointers are copied: a modified copy of the whole argument block would live in scratch
     // memory, because the covariance factor's block table in it is indexed at run time.)
@@ -154,7 +181,7 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
 
     const int ntiles = (g.n_local + kTile - 1) / kTile;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = block; tile < ntiles; tile += nblocks) {
         const int cand = tile * kTile + slot;
         const bool live = cand < g.n_local;
         const int c = live ? cand : g.n_local - 1;  // idle groups shadow the last row (shuffles need all lanes)
@@ -317,26 +344,32 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g)
     }
 #ifdef LMCMA_DIAG
     st[6] = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1)
+    if (threadIdx.x == 0 && block == nblocks - 1)
         for (int q = 0; q < 7; ++q) g_generate_stamps[q] = st[q];
 #endif
 }
 
 #undef GEN_STAMP
 
-template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV>
-hipError_t launch_t(hipStream_t s, const GenParams &g, size_t lds, int blocks)
+template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV, bool PRE>
+hipError_t launch_t(hipStream_t s, const GenParams &g, size_t lds, int blocks, const UpdateArgs *pre)
 {
+    UpdateArgs u{};
+    if (PRE) {
+        u = *pre;
+        lds = std::max(lds, update_pre_lds_doubles(u.N, u.m) * sizeof(double));
+    }
     {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_generate<J, D, GRID_LDS, VB_LDS, COV>), lds);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_generate<J, D, GRID_LDS, VB_LDS, COV, PRE>), lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_generate<J, D, GRID_LDS, VB_LDS, COV>), dim3(blocks, g.batch.queries), dim3(256), lds, s, g);
+    hipLaunchKernelGGL((k_generate<J, D, GRID_LDS, VB_LDS, COV, PRE>), dim3(blocks + (PRE ? 1 : 0), g.batch.queries),
+                       dim3(256), lds, s, g, u);
     return hipGetLastError();
 }
 
 template <int J, int D>
-hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds)
+hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds, const UpdateArgs *pre, bool *pre_done)
 {
     const int ntiles = (g.n_local + kTile - 1) / kTile;
     const size_t rows_b = (size_t)kTile * padded_row_floats(D, g.cost.W) * sizeof(float);
@@ -362,25 +395,34 @@ hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds)
         blocks = std::min(blocks, std::max(per_query, 1));
     }
     if (cov) {
-        if (vb_lds) return launch_t<J, D, false, true, true>(s, g, lds, blocks);
-        return launch_t<J, D, false, false, true>(s, g, lds, blocks);
+        if (vb_lds) return launch_t<J, D, false, true, true, false>(s, g, lds, blocks, nullptr);
+        return launch_t<J, D, false, false, true, false>(s, g, lds, blocks, nullptr);
     }
     if (grid_lds) {
-        if (vb_lds) return launch_t<J, D, true, true, false>(s, g, lds, blocks);
-        return launch_t<J, D, true, false, false>(s, g, lds, blocks);
+        if (vb_lds) return launch_t<J, D, true, true, false, false>(s, g, lds, blocks, nullptr);
+        return launch_t<J, D, true, false, false, false>(s, g, lds, blocks, nullptr);
     }
-    if (vb_lds) return launch_t<J, D, false, true, false>(s, g, lds, blocks);
-    return launch_t<J, D, false, false, false>(s, g, lds, blocks);
+    // the first part of the update as one more workgroup (see k_generate): stores of 17 to 32
+    // vectors whose register tile exists for this row length
+    static const bool no_pre = getenv("LMCMA_HIP_UPDATE_ONE_KERNEL") != nullptr;
+    if (pre && !no_pre && pre->m <= 32 && pre_emax_for(J, pre->N) > 0 && update_emax(pre->N) <= pre_emax_for(J, pre->N) &&
+        update_is_split(pre->N, pre->m) && !update_pre_rides_with_ranking(pre->m)) {
+        if (pre_done) *pre_done = true;
+        if (vb_lds) return launch_t<J, D, false, true, false, true>(s, g, lds, blocks, pre);
+        return launch_t<J, D, false, false, false, true>(s, g, lds, blocks, pre);
+    }
+    if (vb_lds) return launch_t<J, D, false, true, false, false>(s, g, lds, blocks, nullptr);
+    return launch_t<J, D, false, false, false, false>(s, g, lds, blocks, nullptr);
 }
 
 template <int D>
-hipError_t launch_d(hipStream_t s, const GenParams &g, bool grid_lds)
+hipError_t launch_d(hipStream_t s, const GenParams &g, bool grid_lds, const UpdateArgs *pre, bool *pre_done)
 {
     switch ((g.ld + 127) / 128) {
-        case 1: return launch_jd<1, D>(s, g, grid_lds);
-        case 2: return launch_jd<2, D>(s, g, grid_lds);
-        case 3: return launch_jd<3, D>(s, g, grid_lds);
-        case 4: return launch_jd<4, D>(s, g, grid_lds);
+        case 1: return launch_jd<1, D>(s, g, grid_lds, pre, pre_done);
+        case 2: return launch_jd<2, D>(s, g, grid_lds, pre, pre_done);
+        case 3: return launch_jd<3, D>(s, g, grid_lds, pre, pre_done);
+        case 4: return launch_jd<4, D>(s, g, grid_lds, pre, pre_done);
         default: return hipErrorInvalidValue;
     }
 }
@@ -394,8 +436,10 @@ extern "C" hipError_t lmcma_diag_generate_stamps(unsigned long long *out16)
 }
 #endif
 
-hipError_t launch_generate(hipStream_t s, const GenParams &g, int dims, bool grid_lds)
+hipError_t launch_generate(hipStream_t s, const GenParams &g, int dims, bool grid_lds, const UpdateArgs *pre,
+                           bool *pre_done)
 {
+    if (pre_done) *pre_done = false;
     if (g.n_local <= 0) return hipSuccess;
     if (g.batch.queries < 1) return hipErrorInvalidValue;
     if (g.ld <= 0 || (g.ld & 3) || g.ld > 512 || g.cost.W < 1 || dims * g.cost.W > g.ld)
@@ -405,9 +449,9 @@ hipError_t launch_generate(hipStream_t s, const GenParams &g, int dims, bool gri
                     (g.cov.ld & 3)))
         return hipErrorInvalidValue;
     switch (dims) {
-        case 1: return launch_d<1>(s, g, grid_lds);
-        case 2: return launch_d<2>(s, g, grid_lds);
-        case 3: return launch_d<3>(s, g, grid_lds);
+        case 1: return launch_d<1>(s, g, grid_lds, pre, pre_done);
+        case 2: return launch_d<2>(s, g, grid_lds, pre, pre_done);
+        case 3: return launch_d<3>(s, g, grid_lds, pre, pre_done);
         default: return hipErrorInvalidValue;
     }
 }

@@ -694,7 +694,7 @@ hipError_t launch_select(hipStream_t s, const SelectArgs &a, SelectResult *res)
     // The first part of the update as one more workgroup: when the ranking leaves CUs idle
     // (at most one workgroup per CU) and its workgroup is large enough for the vectors.
     int pre_emax = 0;
-    if (a.pre && update_is_split(a.pre->N, a.pre->m) && blocks <= 256 && update_pre_threads(a.pre->m) <= TB &&
+    if (a.pre && update_is_split(a.pre->N, a.pre->m) && update_pre_rides_with_ranking(a.pre->m) && blocks <= 256 && update_pre_threads(a.pre->m) <= TB &&
         a.pre->N <= 256) {  // longer vectors: the stand-alone kernel (fewer variants of this one)
         r.pre = *a.pre;
         r.pre_threads = update_pre_threads(a.pre->m);

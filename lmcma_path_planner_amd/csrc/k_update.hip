@@ -158,11 +158,14 @@ int update_threads(int N, int m) { return update_fits_lds(N, m) ? update_row_thr
 bool update_is_split(int N, int m)
 {
     static const bool off = getenv("LMCMA_HIP_UPDATE_ONE_KERNEL") != nullptr;
-    // Up to 16 vectors.  With 32 the first part (30 dependent steps) outlasts the ranking launch it
-    // rides in by more than the second part saves: measured 64.7 against 61.2 us per generation
-    // (lambda = 8192, N = 144, m = 32).
-    return !off && m >= 1 && threads_for_vectors(m) == 256 && N >= 1 && N <= 512 && update_fits_lds(N, m);
+    // Up to 32 vectors.  With up to 16 the first part rides in the ranking launch; with more it
+    // (30 dependent steps at m = 32) outlasts that launch by more than the second part saves
+    // (measured 64.7 against 61.2 us per generation at lambda = 8192, N = 144, m = 32), so it runs
+    // on a stream of its own beside the sampling and ranking launches (update_pre_rides_with_ranking).
+    return !off && m >= 1 && threads_for_vectors(m) <= 512 && N >= 1 && N <= 512 && update_fits_lds(N, m);
 }
+
+bool update_pre_rides_with_ranking(int m) { return threads_for_vectors(m) == 256; }
 
 int update_pre_threads(int m) { return threads_for_vectors(m); }
 

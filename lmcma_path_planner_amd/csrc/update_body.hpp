@@ -770,6 +770,167 @@ __device__ __forceinline__ void update_pre_body(const UpdateArgs &a, double *s_d
     }
 }
 
+// First part for a workgroup of 256 threads and up to 32 vectors: every 16-lane group owns two
+// slots (grp and grp + 16), so each finished vector is read from LDS once for both and half as
+// many waves meet at the barriers.  This is the form that rides in the sampling launch, whose
+// workgroups have 256 threads.  EMAX >= N / 16.
+template <int EMAX>
+__device__ __forceinline__ void update_pre_body2(const UpdateArgs &a, double *s_dyn)
+{
+    const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
+    const int N = a.N, m = a.m;
+    const OptScalars &o = *a.opt;
+    if (o.done) return;  // nothing is rebuilt once the stop rule has fired (see update_body)
+    const double c1 = o.c1, K = o.K;
+    const int itr = o.itr;
+    constexpr int NP = EMAX * 16;
+    double *s_v = s_dyn;                           // [m][NP] by position, zero beyond N
+    double *s_nv = s_v + (size_t)m * NP;           // [64] |v_i|^2
+    double *s_ljp = s_nv + LMCMA_HIP_MAX_VECTORS;  // [64] lj of the untouched vectors
+
+    int t_reg = 0, vec_reg = 0;
+    if (wl < m) {
+        t_reg = a.t[wl];
+        vec_reg = a.vec[wl];
+    }
+    bool has[2];
+    int slot[2];
+    double lj_old[2];
+    double av[2][EMAX];
+    {
+        // every load before the slot tables are looked at: both the path and the old vector of
+        // both slots (which of the two a vector starts from is known only after the tables)
+        double vold[2][EMAX], pcq[2][EMAX];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            has[q] = grp + 16 * q < m;
+            slot[q] = has[q] ? grp + 16 * q : 0;
+            lj_old[q] = a.lj[slot[q]];
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) {
+                const int n = e * 16 + lane;
+                const size_t at = (size_t)slot[q] * N + (n < N ? n : N - 1);
+                pcq[q][e] = a.pc_arr[at];
+                vold[q][e] = a.v_arr[at];
+            }
+        }
+        asm volatile("" ::: "memory");
+        const SlotPlan sp = slot_plan(t_reg, vec_reg, itr, m, tid);
+        t_reg = sp.t_reg;
+        int pos[2] = {sp.pos, -1};
+        {
+            const int g0 = (tid >> 6) << 2;  // first group of this wave
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned long long hit = __ballot(wl < sp.isz && t_reg == g0 + q + 16);
+                if ((grp & 3) == q && hit != 0ull) pos[1] = __ffsll(hit) - 1;
+            }
+        }
+        const int imin = sp.imin, isz = sp.isz;
+        const double sq = sqrt(1 - c1), ratio = c1 / (1 - c1);
+        bool own[2], rebuild[2];
+        double nrm[2] = {0.0, 0.0};  // squared norm of a rebuilt vector, from its publication
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            own[q] = has[q] && pos[q] >= 0;
+            const bool newest = own[q] && slot[q] == sp.newidx;
+            rebuild[q] = own[q] && pos[q] >= imin && !newest;
+            double aa = 0.0;
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) {
+                const int n = e * 16 + lane;
+                const bool in = own[q] && n < N;
+                av[q][e] = in ? (rebuild[q] ? pcq[q][e] : vold[q][e]) : 0.0;  // L/:376-377
+                aa += av[q][e] * av[q][e];
+            }
+            aa = row16_sum(aa);
+            if (own[q] && !rebuild[q] && !newest) {
+#pragma unroll
+                for (int e = 0; e < EMAX; ++e) s_v[(size_t)pos[q] * NP + e * 16 + lane] = av[q][e];
+                if (lane == 0) {
+                    s_nv[pos[q]] = aa;
+                    s_ljp[pos[q]] = lj_old[q];
+                }
+            }
+        }
+        __syncthreads();
+        // as update_pre_body: vector i is final once it has received T_0 .. T_{i-1}
+        for (int i = 0; i < isz - 2; ++i) {
+            const bool fresh = i >= imin;  // same for every thread
+            if (fresh) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (pos[q] == i && rebuild[q]) {
+                        double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+                        for (int e = 0; e < EMAX; e += 2) {
+                            s_v[(size_t)i * NP + e * 16 + lane] = av[q][e];
+                            s_v[(size_t)i * NP + (e + 1) * 16 + lane] = av[q][e + 1];
+                            q0 += av[q][e] * av[q][e];
+                            q1 += av[q][e + 1] * av[q][e + 1];
+                        }
+                        nrm[q] = row16_sum(q0 + q1);
+                        if (lane == 0) s_nv[i] = nrm[q];
+                    }
+                }
+                __syncthreads();
+            }
+            const bool need0 = rebuild[0] && pos[0] > i, need1 = rebuild[1] && pos[1] > i;
+            if (need0 || need1) {
+                const double *vi = s_v + (size_t)i * NP;
+                double vv[EMAX];
+                double p00 = 0.0, p01 = 0.0, p10 = 0.0, p11 = 0.0;
+#pragma unroll
+                for (int e = 0; e < EMAX; e += 2) {
+                    vv[e] = vi[e * 16 + lane];
+                    vv[e + 1] = vi[(e + 1) * 16 + lane];
+                    p00 += vv[e] * av[0][e];
+                    p01 += vv[e + 1] * av[0][e + 1];
+                    p10 += vv[e] * av[1][e];
+                    p11 += vv[e + 1] * av[1][e + 1];
+                }
+                const double nvi = s_nv[i];
+                const double lji = fresh ? lj_of(nvi, sq, ratio) : s_ljp[i];
+                const double d0 = lji * row16_sum(p00 + p01);
+                const double d1 = lji * row16_sum(p10 + p11);
+                if (need0) {
+#pragma unroll
+                    for (int e = 0; e < EMAX; ++e) av[0][e] = K * av[0][e] - d0 * vv[e];
+                }
+                if (need1) {
+#pragma unroll
+                    for (int e = 0; e < EMAX; ++e) av[1][e] = K * av[1][e] - d1 * vv[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (rebuild[q]) {
+                // L/:386-389; the last vector rebuilt here (position isz - 2) was not published above
+                double aa = nrm[q];
+                if (pos[q] >= isz - 2) {
+                    double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+                    for (int e = 0; e < EMAX; e += 2) {
+                        q0 += av[q][e] * av[q][e];
+                        q1 += av[q][e + 1] * av[q][e + 1];
+                    }
+                    aa = row16_sum(q0 + q1);
+                }
+                if (lane == 0) {
+                    a.nj[slot[q]] = (sq / aa) * (sqrt(1 + ratio * aa) - 1);
+                    a.lj[slot[q]] = lj_of(aa, sq, ratio);
+                }
+#pragma unroll
+                for (int e = 0; e < EMAX; ++e) {
+                    const int n = e * 16 + lane;
+                    if (n < N) a.v_arr[(size_t)slot[q] * N + n] = av[q][e];
+                }
+            }
+        }
+    }
+}
+
 // LDS doubles of the second part when TR threads read the partial rows
 __host__ __device__ inline size_t update_post_lds_doubles(int N, int m, int TR)
 {
