@@ -73,7 +73,55 @@ class OptInfo(ctypes.Structure):
     ]
 
 
-# every symbol include/lmcma_hip.h and include/lmcma_opt.h declare: (restype, argtypes)
+class RosMarker(ctypes.Structure):
+    """lmcma_ros_marker of include/lmcma_ros.h."""
+    _fields_ = [
+        ("frame_id", ctypes.c_char * 32),
+        ("ns", ctypes.c_char * 32),
+        ("id", ctypes.c_int32),
+        ("type", ctypes.c_int32),
+        ("action", ctypes.c_int32),
+        ("position", ctypes.c_double * 3),
+        ("orientation", ctypes.c_double * 4),
+        ("scale", ctypes.c_double * 3),
+        ("color", ctypes.c_float * 4),
+        ("n_points", ctypes.c_int32),
+        ("points", c_double_p),
+    ]
+
+
+class RosPointCloud2(ctypes.Structure):
+    """lmcma_ros_pointcloud2 of include/lmcma_ros.h."""
+    _fields_ = [
+        ("frame_id", ctypes.c_char * 32),
+        ("height", ctypes.c_uint32),
+        ("width", ctypes.c_uint32),
+        ("field_name", (ctypes.c_char * 4) * 3),
+        ("field_offset", ctypes.c_uint32 * 3),
+        ("field_datatype", ctypes.c_uint8 * 3),
+        ("field_count", ctypes.c_uint32 * 3),
+        ("is_bigendian", ctypes.c_uint8),
+        ("point_step", ctypes.c_uint32),
+        ("row_step", ctypes.c_uint32),
+        ("is_dense", ctypes.c_uint8),
+        ("data_bytes", ctypes.c_size_t),
+        ("data", c_uint8_p),
+    ]
+
+
+class RosOctomap(ctypes.Structure):
+    """lmcma_ros_octomap of include/lmcma_ros.h."""
+    _fields_ = [
+        ("frame_id", ctypes.c_char * 32),
+        ("binary", ctypes.c_uint8),
+        ("id", ctypes.c_char * 16),
+        ("resolution", ctypes.c_double),
+        ("data_bytes", ctypes.c_size_t),
+        ("data", ctypes.POINTER(ctypes.c_int8)),
+    ]
+
+
+# every symbol include/lmcma_hip.h, lmcma_opt.h and lmcma_ros.h declare: (restype, argtypes)
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
 SIGNATURES = {
@@ -118,6 +166,14 @@ SIGNATURES = {
     "lmcma_hip_timing_enable": (_i, [_vp, _i]),
     "lmcma_hip_timing_get": (_i, [_vp, c_double_p, c_int64_p]),
     "lmcma_hip_timing_event_overhead": (_i, [_vp, _i, c_double_p]),
+    # lmcma_ros.h
+    "lmcma_ros_path_marker": (_i, [c_double_p, _i, _i, c_double_p, c_double_p, ctypes.c_double, ctypes.c_double,
+                                   c_double_p, _i, ctypes.POINTER(RosMarker)]),
+    "lmcma_ros_path_marker_delete": (_i, [ctypes.POINTER(RosMarker)]),
+    "lmcma_ros_grid_pointcloud2": (_i, [_vp, _i, _i, _i, ctypes.c_double, c_double_p, _vp, ctypes.c_size_t,
+                                        ctypes.POINTER(RosPointCloud2)]),
+    "lmcma_ros_grid_octomap_binary": (_i, [_vp, _i, _i, _i, ctypes.c_double, ctypes.POINTER(ctypes.c_int), _vp,
+                                           ctypes.c_size_t, ctypes.POINTER(RosOctomap)]),
     # lmcma_opt.h
     "lmcma_opt_last_error": (ctypes.c_char_p, []),
     "lmcma_opt_create": (_i, [c_double_p, c_double_p, c_double_p, c_double_p, _i, _i, ctypes.c_double, _i, _i,

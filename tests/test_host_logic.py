@@ -18,10 +18,10 @@ def lib():
 
 def _declared_symbols():
     names = set()
-    for header in ("lmcma_hip.h", "lmcma_opt.h"):
+    for header in ("lmcma_hip.h", "lmcma_opt.h", "lmcma_ros.h"):
         text = open(os.path.join(ROOT, "include", header)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        names |= set(re.findall(r"\b(lmcma_(?:hip|opt|host|grid)_\w+)\s*\(", text))
+        names |= set(re.findall(r"\b(lmcma_(?:hip|opt|host|grid|ros)_\w+)\s*\(", text))
     return names
 
 
