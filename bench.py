@@ -155,6 +155,14 @@ def main():
                     "not the headline workload")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL) for real runs; gloo only to rehearse the "
                     "N > 1 code path on a box with fewer GPUs than ranks")
+    ap.add_argument("--sharded-loop", action="store_true",
+                    help="N = 1 only: go through lmcma_hip_run_sharded with a one-rank RCCL communicator, i.e. "
+                    "what every rank of an N > 1 job runs (not the headline: the graph-replayed lmcma_hip_run is)")
+    ap.add_argument("--exchange", default="library", choices=["library", "torch"],
+                    help="N > 1: 'library' = the sharded loop inside the library (lmcma_hip_run_sharded: RCCL "
+                    "all-gathers queued by the library between its phases, no host code per generation); 'torch' = "
+                    "the same loop driven from Python with torch.distributed all-gathers (the only choice with "
+                    "--backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -181,8 +189,9 @@ def main():
     prob = grids.benchmark_problem(args.config)
     lam_local = prob.lam if args.config <= 3 else prob.lam // 8   # cfg4/5 are quoted as 8-GPU populations
     lam_total = lam_local * world
+    native = world > 1 and args.backend == "nccl" and args.exchange == "library"
     stream = None
-    if world > 1:
+    if world > 1 and not native:
         # kernels and collectives are ordered on one non-default torch stream
         tstream = torch.cuda.Stream(device)
         torch.cuda.set_stream(tstream)
@@ -198,13 +207,36 @@ def main():
         ctx.set_cov_factor(planner.cholesky(planner.covariance(prob.dims, prob.W)))
     ctx.opt_init(prob.x0, prob.sigma0 * (8.0 if args.structured_covariance else 1.0))
 
-    if world == 1:
+    if world == 1 and args.sharded_loop:
+        ctx.comm_init(hip.HipContext.comm_unique_id(), 1, 0)
+
+        def run_steps(k):
+            done = 0
+            while done < k:
+                n = min(EPISODE, k - done)
+                ctx.opt_reset()
+                ctx.run_sharded(n)
+                done += n
+    elif world == 1:
         def run_steps(k):
             done = 0
             while done < k:
                 n = min(EPISODE, k - done)
                 ctx.opt_reset()
                 ctx.run(n)
+                done += n
+    elif native:
+        # one RCCL communicator of the library's own: rank 0 makes the id, torch.distributed carries it
+        uid = [hip.HipContext.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0], world, rank)
+
+        def run_steps(k):
+            done = 0
+            while done < k:
+                n = min(EPISODE, k - done)
+                ctx.opt_reset()
+                ctx.run_sharded(n)
                 done += n
     else:
         shard = shard_mod.HipShard(ctx, device)
@@ -301,8 +333,10 @@ def main():
                        "waypoints": prob.W, "n_params": prob.N, "lambda_per_gpu": lam_local,
                        "lambda_total": lam_total, "m": prob.m, "queries_in_flight": args.queries,
                        "z_source": "philox4x32-10",
-                       "update": "on device, fp64", "episode_generations": EPISODE, "exchange": "all-gather of sorted local costs + all-gather of elite partial sums (N+2 doubles per rank)"
-                       if world > 1 else "none"},
+                       "update": "on device, fp64", "episode_generations": EPISODE,
+                       "exchange": ("all-gather of sorted local costs + all-gather of elite partial sums (N+2 doubles "
+                                    "per rank), " + ("RCCL calls inside the library" if native else
+                                                     "torch.distributed calls from Python")) if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "one generation: " + " + ".join(k for k in per_kernel),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,

@@ -250,6 +250,38 @@ int lmcma_hip_phase_local(lmcma_hip_ctx *ctx);
 int lmcma_hip_phase_rank(lmcma_hip_ctx *ctx);
 int lmcma_hip_phase_update(lmcma_hip_ctx *ctx, int n_partials);
 
+/* ---- a population sharded over the GPUs of a node: the loop behind this boundary ------
+ * The reference is one process with no exchange step (its caller's loop is
+ * L/example_lmcma.cpp:47-60); a population of lambda_total candidates sharded over G
+ * processes, one GPU each, exchanges twice per generation: the shards' sorted costs and
+ * one row of N + 2 doubles per shard (weighted elite sum, success-rule count, lowest cost).
+ * These entry points run that loop inside the library with RCCL all-gathers over xGMI queued
+ * on the context's stream between the phases, so a generation needs no host code of the
+ * caller's.  RCCL (librccl.so.1) is opened with dlopen on first use: a single-GPU caller
+ * needs no RCCL at all.
+ *
+ * lmcma_hip_comm_unique_id   ncclGetUniqueId; one process calls it and hands the 128 bytes
+ *                            to the others by its own means (MPI, a file, torch.distributed)
+ * lmcma_hip_comm_init        ncclCommInitRank on the context's device; collective: every rank
+ *                            of the population calls it with the same id.  The context must
+ *                            be rank's shard: lambda_total = world * lambda_local,
+ *                            first_candidate = rank * lambda_local, world <= 64
+ * lmcma_hip_comm_attach      the same with a communicator the caller already has
+ *                            (nccl_comm is an ncclComm_t; it is used, not owned)
+ * lmcma_hip_comm_destroy     ncclCommDestroy of a communicator made by comm_init;
+ *                            lmcma_hip_destroy does it too
+ * lmcma_hip_run_sharded      n generations: phase_local, all-gather of the costs (in place:
+ *                            the shard's block inside the buffer of all costs), phase_rank,
+ *                            all-gather of the rows, phase_update(world).  Every rank makes
+ *                            the same calls; the replicated state stays bit-identical.
+ *                            A one-rank communicator gives the bits of lmcma_hip_run.      */
+#define LMCMA_HIP_UNIQUE_ID_BYTES 128
+int lmcma_hip_comm_unique_id(char id[LMCMA_HIP_UNIQUE_ID_BYTES]);
+int lmcma_hip_comm_init(lmcma_hip_ctx *ctx, const char id[LMCMA_HIP_UNIQUE_ID_BYTES], int world, int rank);
+int lmcma_hip_comm_attach(lmcma_hip_ctx *ctx, void *nccl_comm, int world, int rank);
+int lmcma_hip_comm_destroy(lmcma_hip_ctx *ctx);
+int lmcma_hip_run_sharded(lmcma_hip_ctx *ctx, int n_generations);
+
 typedef struct {
     int32_t itr;          /* generations completed (L/lmcma.hpp:60)              */
     int32_t iterator_sz;  /* active direction vectors                            */

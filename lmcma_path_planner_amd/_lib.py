@@ -155,6 +155,11 @@ SIGNATURES = {
     "lmcma_hip_phase_local": (_i, [_vp]),
     "lmcma_hip_phase_rank": (_i, [_vp]),
     "lmcma_hip_phase_update": (_i, [_vp, _i]),
+    "lmcma_hip_comm_unique_id": (_i, [ctypes.c_char_p]),
+    "lmcma_hip_comm_init": (_i, [_vp, ctypes.c_char_p, _i, _i]),
+    "lmcma_hip_comm_attach": (_i, [_vp, _vp, _i, _i]),
+    "lmcma_hip_comm_destroy": (_i, [_vp]),
+    "lmcma_hip_run_sharded": (_i, [_vp, _i]),
     "lmcma_hip_opt_get": (_i, [_vp, ctypes.POINTER(OptSummary), c_double_p]),
     "lmcma_hip_opt_get_vectors": (_i, [_vp, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                        c_int32_p]),

@@ -1,5 +1,6 @@
 // C ABI of liblmcma_hip: context lifetime, host<->device plumbing and the
 // per-generation launch sequences.  Entry points are documented in lmcma_hip.h.
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -10,6 +11,8 @@
 #include <mutex>
 #include <string>
 #include <vector>
+
+#include <rccl/rccl.h>   // types and enumerators only: the functions are bound with dlsym (rccl_api)
 
 #include "device_funcs.hpp"
 
@@ -178,8 +181,17 @@ struct lmcma_hip_ctx {
     bool have_state = false, have_weights = false, opt_ready = false;
     bool sampled = false, costs_ready = false, selected = false;
 
+    // a population sharded over processes: the RCCL communicator of its shards
+    ncclComm_t comm = nullptr;
+    bool own_comm = false;
+    int world = 0, rank = 0;
+
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
     hipGraph_t graph[2] = {nullptr, nullptr};
+    // two sharded generations, collectives included (lmcma_hip_run_sharded, opt-in)
+    hipGraphExec_t shard_graph_exec = nullptr;
+    hipGraph_t shard_graph = nullptr;
+    int shard_graph_parity = 0;
     hipEvent_t mark[2] = {nullptr, nullptr};
 
     bool timing = false;
@@ -238,6 +250,8 @@ void drop_graph(lmcma_hip_ctx *c)
         if (c->graph_exec[q]) { (void)hipGraphExecDestroy(c->graph_exec[q]); c->graph_exec[q] = nullptr; }
         if (c->graph[q]) { (void)hipGraphDestroy(c->graph[q]); c->graph[q] = nullptr; }
     }
+    if (c->shard_graph_exec) { (void)hipGraphExecDestroy(c->shard_graph_exec); c->shard_graph_exec = nullptr; }
+    if (c->shard_graph) { (void)hipGraphDestroy(c->shard_graph); c->shard_graph = nullptr; }
 }
 
 int fold_events(lmcma_hip_ctx *c)
@@ -728,6 +742,7 @@ int lmcma_hip_destroy(lmcma_hip_ctx *c)
     if (!c) return LMCMA_HIP_OK;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)lmcma_hip_comm_destroy(c);
     drop_graph(c);
     for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (hipEvent_t ev : c->mark)
@@ -1371,6 +1386,205 @@ int lmcma_hip_phase_update(lmcma_hip_ctx *c, int n_partials)
     // n_partials = 0: a single context, its own partial sum is the new mean
     if (n_partials == 0) return do_update(c, c->partial_local, 1, true);
     return do_update(c, c->partial_all, n_partials, true);
+}
+
+/* ---- sharded population: RCCL behind the boundary ------------------------------------ */
+
+namespace {
+
+// The few RCCL functions the sharded loop needs, bound on first use.  In a process that has
+// loaded PyTorch this is PyTorch's own copy of the library (same soname), so there is one
+// RCCL and one HIP runtime in the process.
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+const RcclApi *rccl_api()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so"};
+        for (const char *n : names) {
+            api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+        if (!api.handle) {
+            api.error = std::string("cannot open librccl.so.1: ") + dlerror();
+            return;
+        }
+        auto bind = [&](const char *sym) {
+            void *p = dlsym(api.handle, sym);
+            if (!p && api.error.empty()) api.error = std::string("librccl has no ") + sym;
+            return p;
+        };
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(bind("ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(bind("ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(bind("ncclCommDestroy"));
+        api.CommCount = reinterpret_cast<decltype(api.CommCount)>(bind("ncclCommCount"));
+        api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(bind("ncclCommUserRank"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(bind("ncclAllGather"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(bind("ncclGetErrorString"));
+    });
+    return &api;
+}
+
+#define RCCL_TRY(api, expr)                                                                        \
+    do {                                                                                           \
+        ncclResult_t _r = (expr);                                                                  \
+        if (_r != ncclSuccess)                                                                     \
+            return fail(LMCMA_HIP_ERR_RUNTIME, std::string(#expr) + ": " + (api)->GetErrorString(_r)); \
+    } while (0)
+
+int check_shard(const lmcma_hip_ctx *c, int world, int rank)
+{
+    if (world < 1 || world > kMaxPartials || rank < 0 || rank >= world)
+        return fail(LMCMA_HIP_ERR_ARG, "comm: world must be in [1, 64] and rank in [0, world)");
+    if (c->Q > 1) return fail(LMCMA_HIP_ERR_STATE, "comm: a context with several queries is not a shard");
+    if ((long)c->nloc * world != c->lambda || c->first != rank * c->nloc)
+        return fail(LMCMA_HIP_ERR_STATE, "comm: the context is not this rank's shard (lambda_total = world * "
+                                         "lambda_local and first_candidate = rank * lambda_local are needed)");
+    return LMCMA_HIP_OK;
+}
+
+}  // namespace
+
+int lmcma_hip_comm_unique_id(char id[LMCMA_HIP_UNIQUE_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) == LMCMA_HIP_UNIQUE_ID_BYTES, "ncclUniqueId is 128 bytes");
+    if (!id) return fail(LMCMA_HIP_ERR_ARG, "null id");
+    const RcclApi *api = rccl_api();
+    if (!api->error.empty()) return fail(LMCMA_HIP_ERR_UNSUPPORTED, api->error);
+    ncclUniqueId u;
+    RCCL_TRY(api, api->GetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_comm_init(lmcma_hip_ctx *c, const char id[LMCMA_HIP_UNIQUE_ID_BYTES], int world, int rank)
+{
+    CTX_TRY(c);
+    if (!id) return fail(LMCMA_HIP_ERR_ARG, "null id");
+    if (c->comm) return fail(LMCMA_HIP_ERR_STATE, "comm_init: the context has a communicator already");
+    int rc = check_shard(c, world, rank);
+    if (rc != LMCMA_HIP_OK) return rc;
+    const RcclApi *api = rccl_api();
+    if (!api->error.empty()) return fail(LMCMA_HIP_ERR_UNSUPPORTED, api->error);
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclComm_t comm = nullptr;
+    RCCL_TRY(api, api->CommInitRank(&comm, world, u, rank));   // on the context's device (CTX_TRY made it current)
+    c->comm = comm;
+    c->own_comm = true;
+    c->world = world;
+    c->rank = rank;
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_comm_attach(lmcma_hip_ctx *c, void *nccl_comm, int world, int rank)
+{
+    CTX_TRY(c);
+    if (!nccl_comm) return fail(LMCMA_HIP_ERR_ARG, "null communicator");
+    if (c->comm) return fail(LMCMA_HIP_ERR_STATE, "comm_attach: the context has a communicator already");
+    int rc = check_shard(c, world, rank);
+    if (rc != LMCMA_HIP_OK) return rc;
+    const RcclApi *api = rccl_api();
+    if (!api->error.empty()) return fail(LMCMA_HIP_ERR_UNSUPPORTED, api->error);
+    int count = 0, urank = -1;
+    RCCL_TRY(api, api->CommCount(static_cast<ncclComm_t>(nccl_comm), &count));
+    RCCL_TRY(api, api->CommUserRank(static_cast<ncclComm_t>(nccl_comm), &urank));
+    if (count != world || urank != rank) return fail(LMCMA_HIP_ERR_ARG, "comm_attach: world / rank differ from the communicator's");
+    c->comm = static_cast<ncclComm_t>(nccl_comm);
+    c->own_comm = false;
+    c->world = world;
+    c->rank = rank;
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_comm_destroy(lmcma_hip_ctx *c)
+{
+    if (!c) return fail(LMCMA_HIP_ERR_ARG, "null context");
+    if (c->comm && c->own_comm) {
+        (void)hipSetDevice(c->cfg.device);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        const RcclApi *api = rccl_api();
+        if (api->CommDestroy) (void)api->CommDestroy(c->comm);
+    }
+    if (c->comm) drop_graph(c);   // a recorded sharded generation holds this communicator's collectives
+    c->comm = nullptr;
+    c->own_comm = false;
+    c->world = 0;
+    c->rank = 0;
+    return LMCMA_HIP_OK;
+}
+
+namespace {
+
+int sharded_generation(lmcma_hip_ctx *c, const RcclApi *api)
+{
+    const int row = c->N + 2;
+    int rc = lmcma_hip_phase_local(c);
+    if (rc != LMCMA_HIP_OK) return rc;
+    // in place: this shard's block lies at its offset inside the buffer of all costs
+    RCCL_TRY(api, api->AllGather(c->cost_all + c->first, c->cost_all, (size_t)c->nloc, ncclFloat32, c->comm, c->stream));
+    if ((rc = lmcma_hip_phase_rank(c)) != LMCMA_HIP_OK) return rc;
+    RCCL_TRY(api, api->AllGather(c->partial_local, c->partial_all, (size_t)row, ncclFloat64, c->comm, c->stream));
+    return lmcma_hip_phase_update(c, c->world);
+}
+
+}  // namespace
+
+int lmcma_hip_run_sharded(lmcma_hip_ctx *c, int n_generations)
+{
+    CTX_TRY(c);
+    if (!c->comm) return fail(LMCMA_HIP_ERR_STATE, "run_sharded: comm_init or comm_attach must come first");
+    if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
+    if (n_generations < 0) return fail(LMCMA_HIP_ERR_ARG, "negative generation count");
+    const RcclApi *api = rccl_api();
+    int left = n_generations;
+    // Opt-in (LMCMA_HIP_SHARD_GRAPH=1): two generations, collectives included, recorded into one
+    // HIP graph and replayed (two because the sorted-cost buffers alternate).  Queuing a generation
+    // from the host takes ~17 us without it, well below a sharded generation's device time, so the
+    // default is the plain loop; every rank of a population must make the same choice.
+    static const bool want_graph = getenv("LMCMA_HIP_SHARD_GRAPH") != nullptr && getenv("LMCMA_HIP_NO_GRAPH") == nullptr;
+    if (want_graph && !c->timing && left > 0) {
+        if (!c->shard_graph_exec) {
+            if (!c->warmed) {
+                int rc = sharded_generation(c, api);   // module loads and LDS attribute calls stay out of the capture
+                if (rc != LMCMA_HIP_OK) return rc;
+                --left;
+                c->warmed = true;
+            }
+            c->shard_graph_parity = c->parity;
+            HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            int crc = LMCMA_HIP_OK;
+            for (int g = 0; g < 2 && crc == LMCMA_HIP_OK; ++g) crc = sharded_generation(c, api);
+            hipError_t e = hipStreamEndCapture(c->stream, &c->shard_graph);
+            if (crc != LMCMA_HIP_OK) { drop_graph(c); return crc; }
+            if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
+            e = hipGraphInstantiate(&c->shard_graph_exec, c->shard_graph, nullptr, nullptr, 0);
+            if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+        }
+        if (left > 0 && c->parity != c->shard_graph_parity) {
+            int rc = sharded_generation(c, api);
+            if (rc != LMCMA_HIP_OK) return rc;
+            --left;
+        }
+        for (; left >= 2; left -= 2) HIP_TRY(hipGraphLaunch(c->shard_graph_exec, c->stream));
+    }
+    for (; left > 0; --left) {
+        int rc = sharded_generation(c, api);
+        if (rc != LMCMA_HIP_OK) return rc;
+    }
+    return LMCMA_HIP_OK;
 }
 
 int lmcma_hip_opt_get(lmcma_hip_ctx *c, lmcma_hip_opt_summary *summary, double *xmean)

@@ -213,6 +213,30 @@ class HipContext:
     def phase_update(self, n_partials=0):
         check_hip(self.lib.lmcma_hip_phase_update(self._h, int(n_partials)), "lmcma_hip_phase_update")
 
+    # ---- a population sharded over processes: RCCL inside the library ----------------
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes from ncclGetUniqueId; one process makes them, every rank passes them to comm_init."""
+        buf = ctypes.create_string_buffer(128)
+        check_hip(_lib.load().lmcma_hip_comm_unique_id(buf), "lmcma_hip_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, unique_id, world, rank):
+        if len(unique_id) != 128:
+            raise ValueError("the unique id has 128 bytes")
+        check_hip(self.lib.lmcma_hip_comm_init(self._h, bytes(unique_id), int(world), int(rank)),
+                  "lmcma_hip_comm_init")
+
+    def comm_attach(self, nccl_comm, world, rank):
+        check_hip(self.lib.lmcma_hip_comm_attach(self._h, ctypes.c_void_p(nccl_comm), int(world), int(rank)),
+                  "lmcma_hip_comm_attach")
+
+    def comm_destroy(self):
+        check_hip(self.lib.lmcma_hip_comm_destroy(self._h), "lmcma_hip_comm_destroy")
+
+    def run_sharded(self, generations):
+        check_hip(self.lib.lmcma_hip_run_sharded(self._h, int(generations)), "lmcma_hip_run_sharded")
+
     def opt_get(self):
         sm = OptSummary()
         xm = np.empty(self.N, dtype=np.float64)

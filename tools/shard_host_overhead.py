@@ -5,7 +5,9 @@
 A one-rank RCCL group stands in for the node: the collectives move nothing but go through
 the same torch / RCCL launch path, and the kernels see the buffer sizes of a 2-rank job.
 Prints the wall time per generation of (a) the library phases alone, (b) phases +
-collectives as bench.py issues them, and (c) the host time to enqueue (b) without waiting."""
+collectives as bench.py --exchange torch issues them, (c) the host time to enqueue (b) without
+waiting, and (d) the same for the loop inside the library (lmcma_hip_run_sharded with a one-rank
+communicator of its own: phases and RCCL calls queued from C++)."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
@@ -69,4 +71,21 @@ print("phases only:        enqueue %.1f us, complete %.1f us per generation" % (
 e, a = timed(with_collectives)
 print("with 2 collectives: enqueue %.1f us, complete %.1f us per generation" % (e, a))
 ctx.close()
+
+# (d) the loop inside the library
+nat = hip.HipContext(prob.N, prob.lam, prob.m, dims=prob.dims, waypoints=prob.W, seed=42, start=prob.start,
+                     goal=prob.goal)
+nat.set_grid(prob.cells); nat.set_bounds(prob.lo, prob.hi); nat.opt_init(prob.x0, prob.sigma0)
+nat.comm_init(hip.HipContext.comm_unique_id(), 1, 0)
+nat.run_sharded(20)
+nat.synchronize()
+t0 = time.perf_counter()
+for g0 in range(0, gens, 100):
+    nat.opt_reset()
+    nat.run_sharded(min(100, gens - g0))
+t_enq = time.perf_counter() - t0
+nat.synchronize()
+t_all = time.perf_counter() - t0
+print("inside the library: enqueue %.1f us, complete %.1f us per generation" % (t_enq / gens * 1e6, t_all / gens * 1e6))
+nat.close()
 dist.destroy_process_group()
