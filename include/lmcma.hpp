@@ -98,6 +98,16 @@ public:
     void useDeviceUpdate(bool on);     // default: host fp64 update
     // attaches the grid cost; evaluatePopulation()/step() then score on the GPU
     void setTrajectoryProblem(const LMCMATrajectoryProblem &problem);
+    // One population sharded over `world` processes, one GPU each (the reference is a single
+    // process): this object is shard `rank` and owns candidates [rank lambda / world,
+    // (rank + 1) lambda / world) of the constructor's lambda, which must be a multiple of world.
+    // Needs usePhiloxSampling, useDeviceUpdate and a trajectory problem; step() then runs
+    // lmcma_hip_run_sharded (RCCL all-gathers between the phases) and must be called with the
+    // same argument by every shard; the search state is replicated bit for bit.  uniqueId: the
+    // 128 bytes one process gets from populationUniqueId and hands to the others by its own
+    // means.  population() then fills the rows of the shard's own candidates only.
+    void setPopulationShard(int world, int rank, const char *uniqueId);
+    static void populationUniqueId(char uniqueId[128]);
 
     // ---- batched generation step (after init()) ----------------------------------
     // scores every candidate of the current population on the device and feeds

@@ -37,6 +37,9 @@ int lmcma_opt_destroy(lmcma_opt *o);
 
 /* extensions of include/lmcma.hpp; call before lmcma_opt_init.  m < 1: lambda */
 int lmcma_opt_set_options(lmcma_opt *o, int m, int device, int philox, int device_update);
+/* LMCMA::setPopulationShard of include/lmcma.hpp: this handle is shard `rank` of a population
+ * sharded over `world` processes; unique_id: 128 bytes from lmcma_hip_comm_unique_id      */
+int lmcma_opt_set_shard(lmcma_opt *o, int world, int rank, const char *unique_id);
 int lmcma_opt_set_problem(lmcma_opt *o, int dims, int waypoints, int nx, int ny, int nz,
                           int cell_type, const void *cells, double c_obs, const double *start,
                           const double *goal, double w_len, double w_grid, double w_smooth,

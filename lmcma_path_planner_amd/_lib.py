@@ -189,6 +189,7 @@ SIGNATURES = {
                                    ctypes.POINTER(_vp)]),
     "lmcma_opt_destroy": (_i, [_vp]),
     "lmcma_opt_set_options": (_i, [_vp, _i, _i, _i, _i]),
+    "lmcma_opt_set_shard": (_i, [_vp, _i, _i, ctypes.c_char_p]),
     "lmcma_opt_set_problem": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_double, c_double_p, c_double_p,
                                    ctypes.c_double, ctypes.c_double, ctypes.c_double, _i]),
     "lmcma_opt_init": (_i, [_vp, _i]),

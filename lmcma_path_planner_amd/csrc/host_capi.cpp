@@ -125,6 +125,15 @@ int lmcma_opt_set_options(lmcma_opt *o, int m, int device, int philox, int devic
     });
 }
 
+int lmcma_opt_set_shard(lmcma_opt *o, int world, int rank, const char *unique_id)
+{
+    if (!o) { g_err = "null handle"; return -1; }
+    return guarded([&] {
+        if (!o->opt) throw std::invalid_argument("SepCMA / CMAChol: one process only");
+        o->opt->setPopulationShard(world, rank, unique_id);
+    });
+}
+
 int lmcma_opt_set_problem(lmcma_opt *o, int dims, int waypoints, int nx, int ny, int nz, int cell_type,
                           const void *cells, double c_obs, const double *start, const double *goal,
                           double w_len, double w_grid, double w_smooth, int pad_mode)

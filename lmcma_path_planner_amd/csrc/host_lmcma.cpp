@@ -248,6 +248,8 @@ struct LMCMA::Impl {
     // options
     int mArg = 0, device = 0;
     bool philox = false, deviceUpdate = false, haveProblem = false;
+    int world = 1, rank = 0;      // setPopulationShard
+    std::string uniqueId;
     LMCMATrajectoryProblem problem;
     std::vector<uint8_t> cellStore;
 
@@ -274,7 +276,7 @@ struct LMCMA::Impl {
     void fetchRows()
     {
         if (rowsFresh) return;
-        hip(lmcma_hip_get_rows(ctx, 0, lambda, rows.data()), "lmcma_hip_get_rows");
+        hip(lmcma_hip_get_rows(ctx, 0, lambda / world, rows.data()), "lmcma_hip_get_rows");
         rowsFresh = true;
     }
 };
@@ -307,6 +309,21 @@ void LMCMA::setDirectionVectors(int m) { impl->mArg = m; }
 void LMCMA::setDevice(int ordinal) { impl->device = ordinal; }
 void LMCMA::usePhiloxSampling(bool on) { impl->philox = on; }
 void LMCMA::useDeviceUpdate(bool on) { impl->deviceUpdate = on; }
+
+void LMCMA::setPopulationShard(int world, int rank, const char *uniqueId)
+{
+    if (impl->initialised) throw std::runtime_error("setPopulationShard must come before init");
+    if (world < 1 || rank < 0 || rank >= world || !uniqueId) throw std::invalid_argument("setPopulationShard: bad world / rank / id");
+    impl->world = world;
+    impl->rank = rank;
+    impl->uniqueId.assign(uniqueId, uniqueId + LMCMA_HIP_UNIQUE_ID_BYTES);
+}
+
+void LMCMA::populationUniqueId(char uniqueId[128])
+{
+    if (lmcma_hip_comm_unique_id(uniqueId) != LMCMA_HIP_OK)
+        throw std::runtime_error(std::string("lmcma_hip_comm_unique_id: ") + lmcma_hip_last_error());
+}
 
 void LMCMA::setTrajectoryProblem(const LMCMATrajectoryProblem &p)
 {
@@ -386,8 +403,12 @@ void LMCMA::init(int N)
     cfg.dims = d.haveProblem ? d.problem.dims : 0;
     cfg.waypoints = d.haveProblem ? d.problem.waypoints : 0;
     cfg.n_params = N;
-    cfg.lambda_total = cfg.lambda_local = d.lambda;
-    cfg.first_candidate = 0;
+    const bool sharded = !d.uniqueId.empty();
+    if (sharded && !(d.deviceUpdate && d.lambda % d.world == 0))
+        throw std::invalid_argument("setPopulationShard needs useDeviceUpdate and lambda a multiple of world");
+    cfg.lambda_total = d.lambda;
+    cfg.lambda_local = d.lambda / d.world;
+    cfg.first_candidate = d.rank * cfg.lambda_local;
     cfg.m = d.m;
     cfg.mu = d.mu;
     cfg.z_source = d.philox ? LMCMA_Z_PHILOX : LMCMA_Z_HOST;
@@ -412,6 +433,7 @@ void LMCMA::init(int N)
                                  d.problem.cell_type, d.problem.c_obs),
               "lmcma_hip_set_grid");
     d.initialised = true;
+    if (sharded) d.hip(lmcma_hip_comm_init(d.ctx, d.uniqueId.data(), d.world, d.rank), "lmcma_hip_comm_init");
     if (d.deviceUpdate) {
         d.hip(lmcma_hip_opt_init(d.ctx, d.xmean.data(), d.sigma), "lmcma_hip_opt_init");
     } else {
@@ -605,7 +627,8 @@ void LMCMA::step(int generations)
         lmcma_hip_opt_summary sm;
         for (int left = generations; left > 0;) {
             const int n = left < 512 ? left : 512;
-            d.hip(lmcma_hip_run(d.ctx, n), "lmcma_hip_run");
+            if (d.uniqueId.empty()) d.hip(lmcma_hip_run(d.ctx, n), "lmcma_hip_run");
+            else d.hip(lmcma_hip_run_sharded(d.ctx, n), "lmcma_hip_run_sharded");
             left -= n;
             d.hip(lmcma_hip_opt_get(d.ctx, &sm, d.xmean.data()), "lmcma_hip_opt_get");
             if (sm.done) break;

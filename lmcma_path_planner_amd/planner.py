@@ -64,6 +64,13 @@ class LMCMA:
         check_opt(self.lib.lmcma_opt_set_options(self._h, int(m), int(device), int(philox), int(device_update)),
                   "lmcma_opt_set_options")
 
+    def setPopulationShard(self, world, rank, unique_id):
+        """This object is shard `rank` of a population sharded over `world` processes (one GPU each)."""
+        if len(unique_id) != 128:
+            raise ValueError("the unique id has 128 bytes")
+        check_opt(self.lib.lmcma_opt_set_shard(self._h, int(world), int(rank), bytes(unique_id)),
+                  "lmcma_opt_set_shard")
+
     def setTrajectoryProblem(self, dims, waypoints, cells, start, goal, cell_type=None, c_obs=1.0, w_len=1.0,
                              w_grid=1000.0, w_smooth=1.0, pad_mode=0):
         cells = np.ascontiguousarray(cells)

@@ -118,3 +118,26 @@ def test_recorded_sharded_generations_give_the_same_bits():
                          timeout=200)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "identical" in out.stdout
+
+
+def test_class_in_shard_mode_with_one_rank_equals_the_plain_class():
+    """LMCMA::setPopulationShard (world 1): step() goes through lmcma_hip_run_sharded."""
+    from lmcma_path_planner_amd import grids, hip, planner
+    prob = grids.benchmark_problem(1)
+
+    def make(shard):
+        o = planner.LMCMA(prob.x0, 64, prob.lo, prob.hi, sigma=prob.sigma0, inseed=42)
+        o.setOptions(m=8, philox=True, device_update=True)
+        if shard:
+            o.setPopulationShard(1, 0, hip.HipContext.comm_unique_id())
+        o.setTrajectoryProblem(prob.dims, prob.W, prob.cells, prob.start, prob.goal)
+        o.init(prob.N)
+        return o
+
+    a, b = make(False), make(True)
+    a.step(40)
+    b.step(40)
+    assert a.counteval == b.counteval == 40 * 64 and a.BestF == b.BestF
+    np.testing.assert_array_equal(a.mean(), b.mean())
+    a.close()
+    b.close()
