@@ -35,7 +35,7 @@ constexpr int kLanes = 32;           // lanes per candidate
 // direction vectors per pass of the sampling loop: 16 float4 loads in flight per lane
 template <int J>
 constexpr int kDirectionsPerPass = J == 1 ? 16 : J == 2 ? 8 : 4;
-constexpr int kTile = 256 / kLanes;  // candidates per block pass
+constexpr int kTile = 256 / kLanes;  // candidates per block pass of a 256-thread workgroup
 constexpr int kBatchBlocks = 2048;   // workgroups of a launch that covers several queries
 
 // floats of a row in LDS with each of its D dimensions padded by two entries on either side
@@ -45,7 +45,8 @@ __host__ __device__ constexpr int padded_row_floats(int D, int W) { return (D * 
 // floats at most; 0: it does not ride.  Rows of more than 256 parameters do not: with 20
 // coordinates per lane the chain of steps, slowed by the sampling workgroups around it, outlasts
 // the sampling by more than the shorter second part gains (lambda = 16384, N = 288, m = 32:
-// 119 against 114 us per generation).
+// 119 against 114 us per generation with 256-thread sampling workgroups, 105 against 98 with
+// 512-thread ones).
 __host__ __device__ constexpr int pre_emax_for(int J, int N)
 {
     return J == 1 ? 8 : J == 2 ? (N <= 192 ? 12 : 16) : 0;
@@ -58,11 +59,17 @@ __host__ __device__ constexpr int pre_emax_for(int J, int N)
 // L/lmcma.cpp:375-390 for all but the newest), which reads and writes nothing the sampling or
 // ranking kernels touch and is too long to ride in the ranking launch when there are more than
 // 16 vectors.  The other workgroups are numbered from 1.
-template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV, bool PRE>
-__global__ __launch_bounds__(256) void k_generate(const GenParams g, const UpdateArgs pre)
+// TB: threads per workgroup, 256 or 512 (TB / 32 candidates per pass).  The LDS copies of 32
+// long direction vectors leave room for one or two workgroups per CU; the larger workgroup
+// then has twice the waves share one copy.
+template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV, bool PRE, int TB>
+__global__ __launch_bounds__(TB) void k_generate(const GenParams g, const UpdateArgs pre)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int kTile = TB / kLanes;
+    static_assert(TB == 256 || ((TB == 512) && !COV && !GRID_LDS), "the wide workgroup: plain variants only");
     if (PRE && blockIdx.x == 0) {
+        if (threadIdx.x >= 256) return;  // the first part of the update is a 256-thread workgroup
         // This workgroup is a chain of dependent steps that shares its CU with sampling workgroups:
         // its waves get the instruction issue ahead of theirs.
         __builtin_amdgcn_s_setprio(3);
@@ -130,25 +137,38 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g, const Updat
         const float4 *srcV = reinterpret_cast<const float4 *>(q_V);
         const float4 *srcB = reinterpret_cast<const float4 *>(q_B);
         float4 *dstV = reinterpret_cast<float4 *>(sV), *dstB = reinterpret_cast<float4 *>(sB);
-        for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * 256) {
-            float4 tv[4], tb[4];
+        // Only the rows' own chunks are read (m * nchunks float4 per matrix), in batches of SB per
+        // thread and matrix that are all requested before the first LDS store: the update wrote
+        // these rows on another XCD, so every batch is a round trip to memory, and 32 vectors of up
+        // to 256 floats go in one.  The padding (beyond the row, and rows from m on) is zeroed
+        // without a load.
+        constexpr int SB = J == 1 ? 4 : TB == 512 ? 4 : 8;
+        const int nreal = g.m * nchunks;
+        for (int i0 = threadIdx.x; i0 < nreal; i0 += SB * TB) {
+            float4 tv[SB], tb[SB];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 256;
-                const int row = i / (LDP >> 2), col = i % (LDP >> 2);
-                const int at = (row < g.m ? row : g.m - 1) * nchunks + (col < nchunks ? col : nchunks - 1);
+            for (int u = 0; u < SB; ++u) {
+                const int i = i0 + u * TB;
+                const int at = i < nreal ? i : nreal - 1;
                 tv[u] = srcV[at];
                 tb[u] = srcB[at];
             }
             asm volatile("" ::: "memory");  // the loads of a batch are all issued before the first LDS store
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 256;
-                if (i < n4) {
-                    const bool pad = i % (LDP >> 2) >= nchunks || i / (LDP >> 2) >= k;
-                    dstV[i] = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : tv[u];
-                    dstB[i] = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : tb[u];
+            for (int u = 0; u < SB; ++u) {
+                const int i = i0 + u * TB;
+                if (i < nreal) {
+                    const int row = i / nchunks, col = i - row * nchunks;
+                    const bool pad = row >= k;   // vectors not in use yet
+                    dstV[row * (LDP >> 2) + col] = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : tv[u];
+                    dstB[row * (LDP >> 2) + col] = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : tb[u];
                 }
+            }
+        }
+        for (int i = threadIdx.x; i < n4; i += TB) {
+            if (i % (LDP >> 2) >= nchunks || i / (LDP >> 2) >= g.m) {
+                dstV[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                dstB[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     }
@@ -171,7 +191,7 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g, const Updat
     if (GRID_LDS) {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.grid);
         uint4 *dst = reinterpret_cast<uint4 *>(sbits);
-        for (int i = threadIdx.x; i < (p.grid_words >> 2); i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (p.grid_words >> 2); i += TB) dst[i] = src[i];
         bits = sbits;
     } else {
         bits = reinterpret_cast<const uint32_t *>(p.grid);
@@ -351,7 +371,7 @@ __global__ __launch_bounds__(256) void k_generate(const GenParams g, const Updat
 
 #undef GEN_STAMP
 
-template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV, bool PRE>
+template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV, bool PRE, int TB = 256>
 hipError_t launch_t(hipStream_t s, const GenParams &g, size_t lds, int blocks, const UpdateArgs *pre)
 {
     UpdateArgs u{};
@@ -360,19 +380,19 @@ hipError_t launch_t(hipStream_t s, const GenParams &g, size_t lds, int blocks, c
         lds = std::max(lds, update_pre_lds_doubles(u.N, u.m) * sizeof(double));
     }
     {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_generate<J, D, GRID_LDS, VB_LDS, COV, PRE>), lds);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_generate<J, D, GRID_LDS, VB_LDS, COV, PRE, TB>), lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_generate<J, D, GRID_LDS, VB_LDS, COV, PRE>), dim3(blocks + (PRE ? 1 : 0), g.batch.queries),
-                       dim3(256), lds, s, g, u);
+    hipLaunchKernelGGL((k_generate<J, D, GRID_LDS, VB_LDS, COV, PRE, TB>), dim3(blocks + (PRE ? 1 : 0), g.batch.queries),
+                       dim3(TB), lds, s, g, u);
     return hipGetLastError();
 }
 
 template <int J, int D>
 hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds, const UpdateArgs *pre, bool *pre_done)
 {
-    const int ntiles = (g.n_local + kTile - 1) / kTile;
-    const size_t rows_b = (size_t)kTile * padded_row_floats(D, g.cost.W) * sizeof(float);
+    const size_t row_b = (size_t)padded_row_floats(D, g.cost.W) * sizeof(float);
+    size_t rows_b = kTile * row_b;
     constexpr int U = kDirectionsPerPass<J>;
     const size_t vb_b = 2 * (size_t)((g.m + U - 1) / U * U) * (J * 128) * sizeof(float);  // whole passes of padded rows
     const bool cov = g.cov.L != nullptr;
@@ -382,11 +402,23 @@ hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds, const Upd
     const size_t budget = 160 * 1024;
     const bool vb_lds = rows_b + vb_b + grid_b + cov_b <= budget && g.m <= 32;
     if (grid_lds && rows_b + (vb_lds ? vb_b : 0) + grid_b > budget) grid_lds = false;
+    // Workgroups of 512 threads (16 candidates per pass) when the staged vectors leave room for
+    // one 256-thread workgroup per CU only: twice the waves then share one LDS copy (lambda =
+    // 16384, N = 288, m = 32 with a 64 MB clearance map: 115 -> 101 us per generation; where two
+    // 256-thread workgroups fit, the wide one gains nothing: N = 144 and 256 measured).
+    bool wide = J >= 2 && vb_lds && !cov && !grid_lds && 2 * kTile * row_b + vb_b <= budget &&
+                2 * (rows_b + vb_b) > budget;
+    if (const char *f = getenv("LMCMA_HIP_GENERATE_THREADS"))
+        wide = J >= 2 && vb_lds && !cov && !grid_lds && 2 * kTile * row_b + vb_b <= budget && atoi(f) == 512;
+    const int tile = wide ? 2 * kTile : kTile;
+    if (wide) rows_b = tile * row_b;
+    const int ntiles = (g.n_local + tile - 1) / tile;
     const size_t lds = rows_b + (vb_lds ? vb_b : 0) + (grid_lds ? grid_b : 0) + cov_b;
     // staging is paid per block: one block per CU when something is staged and there
     // are enough tiles, otherwise one block per tile up to eight blocks per CU
     int blocks = (grid_lds || vb_lds) ? (ntiles < 512 ? ntiles : (grid_lds ? 256 : 512))
                                       : (ntiles < 2048 ? ntiles : 2048);
+    if (wide) blocks = std::min(ntiles, 256);  // one per CU at a time: no second round of staging (101 -> 98 us)
     // several queries: the launch has that many times the workgroups, so each query gets fewer, and a
     // workgroup's staged vectors serve several tiles (about eight workgroups per CU over the launch)
     if (g.batch.queries > 1) {
@@ -408,9 +440,11 @@ hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds, const Upd
     if (pre && !no_pre && pre->m <= 32 && pre_emax_for(J, pre->N) > 0 && update_emax(pre->N) <= pre_emax_for(J, pre->N) &&
         update_is_split(pre->N, pre->m) && !update_pre_rides_with_ranking(pre->m)) {
         if (pre_done) *pre_done = true;
+        if (J >= 2 && wide) return launch_t<J, D, false, true, false, true, (J >= 2 ? 512 : 256)>(s, g, lds, blocks, pre);
         if (vb_lds) return launch_t<J, D, false, true, false, true>(s, g, lds, blocks, pre);
         return launch_t<J, D, false, false, false, true>(s, g, lds, blocks, pre);
     }
+    if (J >= 2 && wide) return launch_t<J, D, false, true, false, false, (J >= 2 ? 512 : 256)>(s, g, lds, blocks, nullptr);
     if (vb_lds) return launch_t<J, D, false, true, false, false>(s, g, lds, blocks, nullptr);
     return launch_t<J, D, false, false, false, false>(s, g, lds, blocks, nullptr);
 }
