@@ -63,7 +63,7 @@ __host__ __device__ constexpr int pre_emax_for(int J, int N)
 // long direction vectors leave room for one or two workgroups per CU; the larger workgroup
 // then has twice the waves share one copy.
 template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV, bool PRE, int TB>
-__global__ __launch_bounds__(TB) void k_generate(const GenParams g, const UpdateArgs pre)
+__device__ __forceinline__ void generate_body(const GenParams &g, const UpdateArgs &pre)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int kTile = TB / kLanes;
@@ -144,6 +144,7 @@ __global__ __launch_bounds__(TB) void k_generate(const GenParams g, const Update
         // without a load.
         constexpr int SB = J == 1 ? 4 : TB == 512 ? 4 : 8;
         const int nreal = g.m * nchunks;
+        const bool dense = nchunks == (LDP >> 2);
         for (int i0 = threadIdx.x; i0 < nreal; i0 += SB * TB) {
             float4 tv[SB], tb[SB];
 #pragma unroll
@@ -158,17 +159,23 @@ __global__ __launch_bounds__(TB) void k_generate(const GenParams g, const Update
             for (int u = 0; u < SB; ++u) {
                 const int i = i0 + u * TB;
                 if (i < nreal) {
-                    const int row = i / nchunks, col = i - row * nchunks;
+                    int row = i / (LDP >> 2), at = i;   // rows that fill their LDS stride
+                    if (!dense) {
+                        row = i / nchunks;
+                        at = row * (LDP >> 2) + (i - row * nchunks);
+                    }
                     const bool pad = row >= k;   // vectors not in use yet
-                    dstV[row * (LDP >> 2) + col] = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : tv[u];
-                    dstB[row * (LDP >> 2) + col] = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : tb[u];
+                    dstV[at] = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : tv[u];
+                    dstB[at] = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : tb[u];
                 }
             }
         }
-        for (int i = threadIdx.x; i < n4; i += TB) {
-            if (i % (LDP >> 2) >= nchunks || i / (LDP >> 2) >= g.m) {
-                dstV[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                dstB[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!dense || g.m < mp) {
+            for (int i = threadIdx.x; i < n4; i += TB) {
+                if (i % (LDP >> 2) >= nchunks || i / (LDP >> 2) >= g.m) {
+                    dstV[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    dstB[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
         }
     }
@@ -371,20 +378,32 @@ __global__ __launch_bounds__(TB) void k_generate(const GenParams g, const Update
 
 #undef GEN_STAMP
 
+// two entry points, so that a launch without the update's first part does not carry its arguments
+template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV, int TB>
+__global__ __launch_bounds__(TB) void k_generate(const GenParams g)
+{
+    generate_body<J, D, GRID_LDS, VB_LDS, COV, false, TB>(g, UpdateArgs{});
+}
+
+template <int J, int D, bool VB_LDS, int TB>
+__global__ __launch_bounds__(TB) void k_generate_pre(const GenParams g, const UpdateArgs pre)
+{
+    generate_body<J, D, false, VB_LDS, false, true, TB>(g, pre);
+}
+
 template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV, bool PRE, int TB = 256>
 hipError_t launch_t(hipStream_t s, const GenParams &g, size_t lds, int blocks, const UpdateArgs *pre)
 {
-    UpdateArgs u{};
-    if (PRE) {
-        u = *pre;
-        lds = std::max(lds, update_pre_lds_doubles(u.N, u.m) * sizeof(double));
-    }
-    {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_generate<J, D, GRID_LDS, VB_LDS, COV, PRE, TB>), lds);
+    if constexpr (PRE) {
+        lds = std::max(lds, update_pre_lds_doubles(pre->N, pre->m) * sizeof(double));
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_generate_pre<J, D, VB_LDS, TB>), lds);
         if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_generate_pre<J, D, VB_LDS, TB>), dim3(blocks + 1, g.batch.queries), dim3(TB), lds, s, g, *pre);
+    } else {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_generate<J, D, GRID_LDS, VB_LDS, COV, TB>), lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_generate<J, D, GRID_LDS, VB_LDS, COV, TB>), dim3(blocks, g.batch.queries), dim3(TB), lds, s, g);
     }
-    hipLaunchKernelGGL((k_generate<J, D, GRID_LDS, VB_LDS, COV, PRE, TB>), dim3(blocks + (PRE ? 1 : 0), g.batch.queries),
-                       dim3(TB), lds, s, g, u);
     return hipGetLastError();
 }
 

@@ -246,7 +246,9 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, 
     const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
     const int N = a.N, m = a.m, lambda = a.lambda;
     OptScalars &o = *a.opt;
-    if (o.done) return;  // the stop rule has fired (L/:426-429): the state stays as it is
+    // The stop rule (L/:426-429) is looked at only after every load of the kernel has been
+    // requested (below): a return here would make those requests wait for this scalar's round trip.
+    const int done = o.done;
     const double sigma = o.sigma, cc = o.cc, c1 = o.c1, K = o.K, Mfac = o.M;
     const int itr = o.itr;
     const bool worker = tid < T;
@@ -328,6 +330,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, 
     RowSumBatch first_rows;
     row_sums_begin(a.partials, a.n_partials, N, a.partial_stride, TR, first_rows);
     asm volatile("" ::: "memory");  // no load above is moved below this point
+    if (done) return;  // the stop rule has fired: the state stays as it is
     LMCMA_STAMP(1);
 
     // ---- L/:331-364: which slot receives the new direction.  Every wave works it out for
@@ -656,7 +659,7 @@ __device__ __forceinline__ void update_pre_body(const UpdateArgs &a, double *s_d
     if (tid >= T) return;
     const int N = a.N, m = a.m;
     const OptScalars &o = *a.opt;
-    if (o.done) return;  // nothing is rebuilt once the stop rule has fired (see update_body)
+    const int done = o.done;  // looked at after the loads have been requested (see update_body)
     const double c1 = o.c1, K = o.K;
     const int itr = o.itr;
     const bool worker = true;
@@ -686,6 +689,7 @@ __device__ __forceinline__ void update_pre_body(const UpdateArgs &a, double *s_d
         }
     }
     asm volatile("" ::: "memory");
+    if (done) return;  // nothing is rebuilt once the stop rule has fired
     const SlotPlan sp = slot_plan(t_reg, vec_reg, itr, m, tid);
     const int imin = sp.imin, isz = sp.isz, pos = sp.pos;
     const bool own = has_slot && pos >= 0;
@@ -780,7 +784,7 @@ __device__ __forceinline__ void update_pre_body2(const UpdateArgs &a, double *s_
     const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
     const int N = a.N, m = a.m;
     const OptScalars &o = *a.opt;
-    if (o.done) return;  // nothing is rebuilt once the stop rule has fired (see update_body)
+    const int done = o.done;  // looked at after the loads have been requested (see update_body)
     const double c1 = o.c1, K = o.K;
     const int itr = o.itr;
     constexpr int NP = EMAX * 16;
@@ -815,6 +819,7 @@ __device__ __forceinline__ void update_pre_body2(const UpdateArgs &a, double *s_
             }
         }
         asm volatile("" ::: "memory");
+        if (done) return;  // nothing is rebuilt once the stop rule has fired
         const SlotPlan sp = slot_plan(t_reg, vec_reg, itr, m, tid);
         t_reg = sp.t_reg;
         int pos[2] = {sp.pos, -1};
@@ -947,7 +952,7 @@ __device__ __forceinline__ void update_post_body(const UpdateArgs &a, double *s_
     const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
     const int N = a.N, m = a.m, lambda = a.lambda;
     OptScalars &o = *a.opt;
-    if (o.done) return;  // see update_body
+    const int done = o.done;  // looked at after the loads have been requested (see update_body)
     const double sigma = o.sigma, cc = o.cc, c1 = o.c1, K = o.K, Mfac = o.M;
     const int itr = o.itr;
     const bool worker = tid < T;
@@ -1015,6 +1020,7 @@ __device__ __forceinline__ void update_post_body(const UpdateArgs &a, double *s_
     RowSumBatch first_rows;
     row_sums_begin(a.partials, a.n_partials, N, a.partial_stride, TR, first_rows);
     asm volatile("" ::: "memory");
+    if (done) return;  // the stop rule has fired: the state stays as it is
     LMCMA_STAMP(1);
 
     const SlotPlan sp = slot_plan(t_reg, vec_reg, itr, m, tid);
