@@ -26,8 +26,10 @@ int main(int argc, char **argv)
 
     LMCMA opt(start, -1, lo, hi, 1.0, 0, seed);  // lambda < 1: 4 + int(3 ln N)
     opt.init(2);
+    CMABase *base = &opt;   // every second evaluation goes through the base class, as a caller holding a CMABase* would
     for (int i = 0; i < evaluations && !opt.isBehaviorLearningDone(); ++i) {
-        opt.getNextParameterVector(x, 2);
+        if (i & 1) base->getNextParameterVector(x, 2);
+        else opt.getNextParameterVector(x, 2);
         double f = two_bumps(x[0], x[1]);
         opt.setEvaluationFeedback(&f, 1);
     }

@@ -7,7 +7,9 @@
 // free functions it declares (RNG :32-36, myqsort :37-38, covariance :248,
 // differentiationMatrix :250-251, invert / cholesky / applyCovL :252-254).
 // A caller written against the reference header compiles against this one
-// unchanged and links liblmcma_hip.so instead of lmcma.cpp.
+// unchanged and links liblmcma_hip.so instead of lmcma.cpp; so does an optimiser
+// derived from CMABase (:41-81: its protected state, constructor and pure virtual
+// sample() / update() are kept).
 //
 // What runs where: the population work (LMCMA::sample and, with a trajectory
 // problem attached, cost evaluation, ranking and recombination) runs on the GPU
@@ -63,17 +65,57 @@ struct LMCMATrajectoryProblem {
     int pad_mode = 0;              // LMCMA_PAD_ENDPOINT
 };
 
+// The base class of the reference (lmcma.hpp:41-81) with its protected state, its constructor
+// and its pure virtual sample() / update(), so that an optimiser a caller derived from the
+// reference's CMABase compiles and runs against this header: init allocates the population and
+// the recombination weights (lmcma.cpp:130-170), getNextParameterVector hands out row sampleIdx
+// of arx, setEvaluationFeedback sums the feedbacks, keeps counteval / BestF and calls update();
+// sample() after every lambda-th call (lmcma.cpp:172-205).  Such a subclass runs on the host like
+// the reference's; the classes below keep their populations on the GPU and answer the same two
+// calls through the hooks at the end (also through a CMABase pointer).
 class CMABase {
+protected:
+    int N;
+    int lambda;
+    int mu;
+    double mueff;
+    double *initialParams;
+    double *loBounds;
+    double *hiBounds;
+    double *arx;
+    double *arfitness;
+    double *xmean;
+    double *xold;
+    double *weights;
+    double *covariance;
+    int inseed;
+    bool verbose;
+    double *L;
+    int itr;
+    int sampleIdx;
+    random_t ttime;
+
 public:
     int counteval;
     double BestF;
 
-    CMABase() : counteval(0), BestF(1.7976931348623157e308) {}
-    virtual ~CMABase() {}
-    virtual void init(int N) = 0;
-    virtual void getNextParameterVector(double *params, int N) = 0;
-    virtual void setEvaluationFeedback(double *feedbacks, int numFeedbacks) = 0;
-    virtual bool isBehaviorLearningDone() { return false; }
+    CMABase(double *initialParams, int lambda, double *loBounds, double *hiBounds, double *covariance, int inseed,
+            bool verbose = false);
+    virtual ~CMABase();
+    virtual void init(int N);
+    void getNextParameterVector(double *params, int N);
+    void setEvaluationFeedback(double *feedbacks, int numFeedbacks);
+    virtual bool isBehaviorLearningDone();
+
+protected:
+    virtual void update() = 0;
+    virtual void sample() = 0;
+    void sampleStandardNormal(double *z);
+    void applyBoundaries();
+    // Not in the reference: the two non-virtual calls above go through these.  The defaults are
+    // the reference's behaviour on arx / arfitness.
+    virtual void askHook(double *params, int N);
+    virtual void tellHook(double *feedbacks, int numFeedbacks);
 };
 
 class LMCMA : public CMABase {
@@ -85,8 +127,6 @@ public:
           double sigma = 1.0, double *covariance = 0, int inseed = 0, bool verbose = false);
     ~LMCMA();
     void init(int N);
-    void getNextParameterVector(double *params, int N);
-    void setEvaluationFeedback(double *feedbacks, int numFeedbacks);
     bool isBehaviorLearningDone();
     void sample();
     void update();
@@ -130,6 +170,10 @@ public:
 
     struct Impl;
 
+protected:
+    void askHook(double *params, int N);       // getNextParameterVector
+    void tellHook(double *feedbacks, int numFeedbacks);   // setEvaluationFeedback
+
 private:
     LMCMA(const LMCMA &);
     LMCMA &operator=(const LMCMA &);
@@ -146,8 +190,6 @@ public:
            double sigma = 1.0, double *covariance = 0, int inseed = 0, bool verbose = false);
     ~SepCMA();
     void init(int N);
-    void getNextParameterVector(double *params, int N);
-    void setEvaluationFeedback(double *feedbacks, int numFeedbacks);
     void sample();
     void update();
 
@@ -166,6 +208,10 @@ public:
 
     struct Impl;
 
+protected:
+    void askHook(double *params, int N);       // getNextParameterVector
+    void tellHook(double *feedbacks, int numFeedbacks);   // setEvaluationFeedback
+
 private:
     SepCMA(const SepCMA &);
     SepCMA &operator=(const SepCMA &);
@@ -183,8 +229,6 @@ public:
             double sigma = 1.0, double *covariance = 0, int inseed = 0, bool verbose = false);
     ~CMAChol();
     void init(int N);
-    void getNextParameterVector(double *params, int N);
-    void setEvaluationFeedback(double *feedbacks, int numFeedbacks);
     void sample();
     void update();
 
@@ -202,6 +246,10 @@ public:
     void population(double *rows_out) const;  // [lambda][N]
 
     struct Impl;
+
+protected:
+    void askHook(double *params, int N);       // getNextParameterVector
+    void tellHook(double *feedbacks, int numFeedbacks);   // setEvaluationFeedback
 
 private:
     CMAChol(const CMAChol &);

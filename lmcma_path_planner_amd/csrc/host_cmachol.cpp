@@ -44,7 +44,7 @@ struct CMAChol::Impl {
 
 CMAChol::CMAChol(double *initialParams, int lambda, double *loBounds, double *hiBounds, double sigma,
                double *covariance, int inseed, bool verbose)
-    : impl(new Impl())
+    : CMABase(initialParams, lambda, loBounds, hiBounds, covariance, inseed, verbose), impl(new Impl())
 {
     impl->initialParams = initialParams;
     impl->lambdaArg = lambda;
@@ -193,7 +193,7 @@ void CMAChol::sample()
     d.rowsFresh = false;
 }
 
-void CMAChol::getNextParameterVector(double *params, int N)
+void CMAChol::askHook(double *params, int N)
 {
     Impl &d = *impl;
     if (!d.initialised) throw std::runtime_error("CMAChol::getNextParameterVector before init");
@@ -202,7 +202,7 @@ void CMAChol::getNextParameterVector(double *params, int N)
     std::copy(&d.rows[(size_t)d.sampleIdx * d.N], &d.rows[(size_t)d.sampleIdx * d.N] + n, params);
 }
 
-void CMAChol::setEvaluationFeedback(double *feedbacks, int numFeedbacks)
+void CMAChol::tellHook(double *feedbacks, int numFeedbacks)
 {
     Impl &d = *impl;
     if (!d.initialised) throw std::runtime_error("CMAChol::setEvaluationFeedback before init");

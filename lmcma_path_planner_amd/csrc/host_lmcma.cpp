@@ -283,7 +283,7 @@ struct LMCMA::Impl {
 
 LMCMA::LMCMA(double *initialParams, int lambda, double *loBounds, double *hiBounds, double sigma,
              double *covariance, int inseed, bool verbose)
-    : impl(new Impl())
+    : CMABase(initialParams, lambda, loBounds, hiBounds, covariance, inseed, verbose), impl(new Impl())
 {
     impl->initialParams = initialParams;
     impl->lambdaArg = lambda;
@@ -472,7 +472,7 @@ void LMCMA::sample()
     d.rowsFresh = false;
 }
 
-void LMCMA::getNextParameterVector(double *params, int N)
+void LMCMA::askHook(double *params, int N)
 {
     Impl &d = *impl;
     if (!d.initialised) throw std::runtime_error("LMCMA::getNextParameterVector before init");
@@ -482,7 +482,7 @@ void LMCMA::getNextParameterVector(double *params, int N)
     std::copy(&d.rows[(size_t)d.sampleIdx * d.N], &d.rows[(size_t)d.sampleIdx * d.N] + n, params);
 }
 
-void LMCMA::setEvaluationFeedback(double *feedbacks, int numFeedbacks)
+void LMCMA::tellHook(double *feedbacks, int numFeedbacks)
 {
     Impl &d = *impl;
     if (!d.initialised) throw std::runtime_error("LMCMA::setEvaluationFeedback before init");

@@ -43,7 +43,7 @@ struct SepCMA::Impl {
 
 SepCMA::SepCMA(double *initialParams, int lambda, double *loBounds, double *hiBounds, double sigma,
                double *covariance, int inseed, bool verbose)
-    : impl(new Impl())
+    : CMABase(initialParams, lambda, loBounds, hiBounds, covariance, inseed, verbose), impl(new Impl())
 {
     impl->initialParams = initialParams;
     impl->lambdaArg = lambda;
@@ -181,7 +181,7 @@ void SepCMA::sample()
     d.rowsFresh = false;
 }
 
-void SepCMA::getNextParameterVector(double *params, int N)
+void SepCMA::askHook(double *params, int N)
 {
     Impl &d = *impl;
     if (!d.initialised) throw std::runtime_error("SepCMA::getNextParameterVector before init");
@@ -190,7 +190,7 @@ void SepCMA::getNextParameterVector(double *params, int N)
     std::copy(&d.rows[(size_t)d.sampleIdx * d.N], &d.rows[(size_t)d.sampleIdx * d.N] + n, params);
 }
 
-void SepCMA::setEvaluationFeedback(double *feedbacks, int numFeedbacks)
+void SepCMA::tellHook(double *feedbacks, int numFeedbacks)
 {
     Impl &d = *impl;
     if (!d.initialised) throw std::runtime_error("SepCMA::setEvaluationFeedback before init");

@@ -213,3 +213,26 @@ def test_readers_on_the_reference_map_files():
     assert occ.shape == (256, 256, 256) and sc == 4.0
     np.testing.assert_allclose(tr, [-1.5, -2.0, -0.001])
     assert 0 < occ.sum() < occ.size // 4
+
+
+def test_user_subclass_of_cmabase_runs_like_the_reference_base_class(oracle):
+    """examples/custom_optimiser.cpp derives from CMABase as a caller of the reference's header
+    would (protected arx / arfitness / xmean / weights, sampleStandardNormal, applyBoundaries,
+    ask/tell through a CMABase pointer).  No GPU involved.  Its first candidate is the initial mean
+    plus sigma times the first normals of the reference's generator (lmcma.cpp:212-215), clamped
+    (:220-230); lambda defaults to 4 + int(3 ln N) (:134-135)."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "bin", "custom_optimiser")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    for seed in (7, 42):
+        out = subprocess.run([exe, str(seed)], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0, out.stdout + out.stderr
+        first = out.stdout.splitlines()[0].split()
+        assert first[:3] == ["lambda", "9", "first"]
+        got = np.array([float(v) for v in first[3:]])
+        x0 = np.array([3.0, -2.0, 1.0, 0.5, -4.0, 2.5])
+        want = np.minimum(np.maximum(x0 + 0.8 * oracle.gauss_stream(seed, 6), -5.0), 3.2)
+        np.testing.assert_array_equal(got, want)
+        m = re.search(r"evaluations (\d+) best ([0-9.e+-]+)", out.stdout)
+        assert int(m.group(1)) == 598 * 9          # sigma 0.8 * 0.97^g < 1e-8 after 598 generations
+        assert float(m.group(2)) < 1e-12
