@@ -135,7 +135,10 @@ public:
     void setDirectionVectors(int m);   // default: lambda, the reference's choice
     void setDevice(int ordinal);       // default 0
     void usePhiloxSampling(bool on);   // default: the reference's sequential RNG on the host
-    void useDeviceUpdate(bool on);     // default: host fp64 update
+    // default: host fp64 update.  With the device update (needs usePhiloxSampling) the state lives on
+    // the device: step() runs whole generations there, and ask/tell still works with the caller's own
+    // cost (candidates drawn on the device, the caller's lambda costs ranked there as floats)
+    void useDeviceUpdate(bool on);
     // attaches the grid cost; evaluatePopulation()/step() then score on the GPU
     void setTrajectoryProblem(const LMCMATrajectoryProblem &problem);
     // One population sharded over `world` processes, one GPU each (the reference is a single

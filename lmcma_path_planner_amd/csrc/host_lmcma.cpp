@@ -260,6 +260,7 @@ struct LMCMA::Impl {
     std::vector<int> slot, born, order;   // t[], vec[], iterator[] of the reference
     std::vector<double> fitness, prevSorted, rows, lastCosts;
     bool rowsFresh = false;
+    bool popReady = false;   // device update: the current generation's candidates have been drawn for ask/tell
     random_t rng;
     bool rngReady = false;
     lmcma_hip_ctx *ctx = 0;
@@ -391,8 +392,8 @@ void LMCMA::init(int N)
     d.s = 0;
     d.active = 0;
 
-    if (d.deviceUpdate && !(d.philox && d.haveProblem))
-        throw std::invalid_argument("useDeviceUpdate needs usePhiloxSampling and a trajectory problem");
+    if (d.deviceUpdate && !d.philox)
+        throw std::invalid_argument("useDeviceUpdate needs usePhiloxSampling (the device draws its own normals)");
     if (d.haveProblem && d.problem.dims * d.problem.waypoints != N)
         throw std::invalid_argument("LMCMA::init: N must equal dims * waypoints of the trajectory problem");
 
@@ -476,7 +477,14 @@ void LMCMA::askHook(double *params, int N)
 {
     Impl &d = *impl;
     if (!d.initialised) throw std::runtime_error("LMCMA::getNextParameterVector before init");
-    if (d.deviceUpdate) throw std::runtime_error("ask/tell is not available with useDeviceUpdate; use step()");
+    if (d.deviceUpdate && !d.popReady) {
+        // the state lives on the device: draw this generation's candidates there (the Philox
+        // counter is the generation number, as inside lmcma_hip_run)
+        if (!d.uniqueId.empty()) throw std::runtime_error("ask/tell is not available for a shard of a population; use step()");
+        d.hip(lmcma_hip_sample(d.ctx, (uint32_t)d.itr, 0), "lmcma_hip_sample");
+        d.rowsFresh = false;
+        d.popReady = true;
+    }
     d.fetchRows();
     const int n = std::min(N, d.N);
     std::copy(&d.rows[(size_t)d.sampleIdx * d.N], &d.rows[(size_t)d.sampleIdx * d.N] + n, params);
@@ -486,7 +494,7 @@ void LMCMA::tellHook(double *feedbacks, int numFeedbacks)
 {
     Impl &d = *impl;
     if (!d.initialised) throw std::runtime_error("LMCMA::setEvaluationFeedback before init");
-    if (d.deviceUpdate) throw std::runtime_error("ask/tell is not available with useDeviceUpdate; use step()");
+    if (d.deviceUpdate && !d.popReady) throw std::runtime_error("setEvaluationFeedback before getNextParameterVector");
     double f = 0.0;
     for (int i = 0; i < numFeedbacks; ++i) f += feedbacks[i];  // left to right, L/:186-188
     d.fitness[d.sampleIdx] = f;
@@ -497,8 +505,23 @@ void LMCMA::tellHook(double *feedbacks, int numFeedbacks)
         if (d.verbose) std::cout << "Functions evaluation #" << counteval << ", value: " << f << std::endl;
     }
     if (++d.sampleIdx % d.lambda == 0) {
-        update();
-        sample();
+        if (d.deviceUpdate) {
+            // the caller's costs go to the device (ranked there as floats), which ranks, recombines
+            // and updates; the next generation is drawn at the next getNextParameterVector
+            lmcma_hip_opt_summary sm;
+            d.hip(lmcma_hip_set_costs(d.ctx, 0, d.lambda, d.fitness.data()), "lmcma_hip_set_costs");
+            d.hip(lmcma_hip_phase_rank(d.ctx), "lmcma_hip_phase_rank");
+            d.hip(lmcma_hip_phase_update(d.ctx, 0), "lmcma_hip_phase_update");
+            d.hip(lmcma_hip_opt_get(d.ctx, &sm, d.xmean.data()), "lmcma_hip_opt_get");
+            d.itr = sm.itr;
+            d.sigma = sm.sigma;
+            d.s = sm.s;
+            d.active = sm.iterator_sz;
+            d.popReady = false;
+        } else {
+            update();
+            sample();
+        }
         d.sampleIdx = 0;
     }
 }
@@ -620,6 +643,7 @@ void LMCMA::step(int generations)
     if (!d.initialised) throw std::runtime_error("LMCMA::step before init");
     if (!d.haveProblem) throw std::runtime_error("step needs setTrajectoryProblem");
     if (generations < 1) return;
+    if (d.sampleIdx != 0) throw std::runtime_error("step in the middle of an ask/tell generation");
     if (d.deviceUpdate) {
         // the library replays captured generations back to back; the stop rule (L/:426-429) is
         // evaluated on the device and freezes the state, and it is looked at here every 512
@@ -640,6 +664,7 @@ void LMCMA::step(int generations)
         counteval = (int)sm.counteval;
         BestF = sm.best_f;
         d.rowsFresh = false;
+        d.popReady = false;
         return;
     }
     for (int g = 0; g < generations; ++g) {

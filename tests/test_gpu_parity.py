@@ -650,8 +650,44 @@ def test_lmcma_class_device_update_mode(oracle, use_cov):
     final, _ = co.cost(opt.mean())
     assert opt.generation == 300 and opt.counteval == 300 * prob.lam
     assert final < straight and opt.BestF < straight
-    with pytest.raises(Exception):
-        opt.getNextParameterVector()
+    opt.close()
+
+
+def test_lmcma_class_ask_tell_with_the_device_update_follows_the_oracle(oracle):
+    """The reference's calling convention (getNextParameterVector / setEvaluationFeedback with the
+    caller's own cost, example_lmcma.cpp:47-54) with the state on the device: candidates drawn
+    there from the Philox stream, the caller's costs sent back, ranking, recombination and the
+    fp64 update on the device.  The oracle is handed the device's rows and the costs as floats
+    (the device ranks floats) and must agree generation by generation."""
+    from lmcma_path_planner_amd import LMCMA
+    N, lam, m, seed = 24, 64, 8, 11
+    x0, lo, hi = np.full(N, 3.0), np.full(N, -4.0), np.full(N, 6.0)
+    scale = 10.0 ** (np.arange(N) / (N - 1))
+    opt = LMCMA(x0, lam, lo, hi, 1.5, None, seed)
+    opt.setOptions(m=m, philox=True, device_update=True)
+    opt.init(N)
+    ref = oracle.OracleLMCMA(N, lam, m, initial=x0, lo=lo, hi=hi, sigma=1.5, seed=seed, z_source=oracle.Z_GIVEN)
+    best = np.inf
+    for g in range(m + 14):
+        rows, costs = [], []
+        for i in range(lam):
+            x = opt.getNextParameterVector()
+            f = float(np.sum(scale * (x - 1.0) ** 2))
+            opt.setEvaluationFeedback([0.5 * f, 0.5 * f])
+            rows.append(x)
+            costs.append(f)
+        rows, costs = np.array(rows), np.array(costs)
+        best = min(best, costs.min())
+        if g == 0:
+            z = np.stack([oracle.philox_normals(seed, 0, i, N) for i in range(lam)])
+            assert np.max(np.abs(rows - np.clip(x0 + 1.5 * z, lo, hi))) <= 2e-5 * 10.0
+        ref.set_arx(rows)
+        ref.update_only(costs.astype(np.float32).astype(np.float64))
+        np.testing.assert_allclose(opt.mean(), ref.xmean, rtol=1e-12, atol=1e-12, err_msg="generation %d" % g)
+        np.testing.assert_allclose(opt.sigma, ref.sigma, rtol=1e-12)
+        assert opt.generation == g + 1 and opt.counteval == (g + 1) * lam
+    assert opt.BestF == best     # kept on the host from the caller's doubles (lmcma.cpp:192-198)
+    assert best < 0.2 * float(np.sum(scale * 4.0))
     opt.close()
 
 
