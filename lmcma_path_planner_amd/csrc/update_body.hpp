@@ -242,7 +242,7 @@ __host__ __device__ inline size_t update_lds_doubles(int N, int m, int TR, bool 
 template <int EMAX, bool V_LDS>
 __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, int T, int TR)
 {
-    constexpr bool KEEP_PC = EMAX <= 8;  // evolution paths stay in registers when they fit
+    constexpr bool KEEP_PC = EMAX <= 16;  // evolution paths stay in registers when they fit (20 per lane spill)
     const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
     const int N = a.N, m = a.m, lambda = a.lambda;
     OptScalars &o = *a.opt;
@@ -948,7 +948,7 @@ __host__ __device__ inline size_t update_post_lds_doubles(int N, int m, int TR)
 template <int EMAX>
 __device__ __forceinline__ void update_post_body(const UpdateArgs &a, double *s_dyn, int T, int TR)
 {
-    constexpr bool KEEP_PC = EMAX <= 8;
+    constexpr bool KEEP_PC = EMAX <= 16;  // the paths stay in registers (re-read at the end otherwise)
     const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
     const int N = a.N, m = a.m, lambda = a.lambda;
     OptScalars &o = *a.opt;
