@@ -78,6 +78,15 @@ __device__ __forceinline__ void generate_body(const GenParams &g, const UpdateAr
         if (J == 1) update_pre_body2<8>(a, s_dyn);
         else if (J == 2 && a.N <= 192) update_pre_body2<12>(a, s_dyn);
         else if (J == 2) update_pre_body2<16>(a, s_dyn);
+#ifdef LMCMA_DIAG
+        if (threadIdx.x == 0) {  // this translation unit's copy of the update's stamps, beside the sampling ones
+            g_generate_stamps[8] = g_update_stamps[6];
+            g_generate_stamps[9] = g_update_stamps[7];
+            g_generate_stamps[10] = g_update_stamps[13];
+            g_generate_stamps[11] = g_update_stamps[14];
+            g_generate_stamps[12] = g_update_stamps[15];
+        }
+#endif
         return;
     }
     const int block = (int)blockIdx.x - (PRE ? 1 : 0), nblocks = (int)gridDim.x - (PRE ? 1 : 0);

@@ -792,6 +792,7 @@ __device__ __forceinline__ void update_pre_body2(const UpdateArgs &a, double *s_
     double *s_nv = s_v + (size_t)m * NP;           // [64] |v_i|^2
     double *s_ljp = s_nv + LMCMA_HIP_MAX_VECTORS;  // [64] lj of the untouched vectors
 
+    LMCMA_STAMP(6);
     int t_reg = 0, vec_reg = 0;
     if (wl < m) {
         t_reg = a.t[wl];
@@ -820,6 +821,7 @@ __device__ __forceinline__ void update_pre_body2(const UpdateArgs &a, double *s_
         }
         asm volatile("" ::: "memory");
         if (done) return;  // nothing is rebuilt once the stop rule has fired
+        LMCMA_STAMP(7);
         const SlotPlan sp = slot_plan(t_reg, vec_reg, itr, m, tid);
         t_reg = sp.t_reg;
         int pos[2] = {sp.pos, -1};
@@ -859,6 +861,7 @@ __device__ __forceinline__ void update_pre_body2(const UpdateArgs &a, double *s_
             }
         }
         __syncthreads();
+        LMCMA_STAMP(13);
         // as update_pre_body: vector i is final once it has received T_0 .. T_{i-1}
         for (int i = 0; i < isz - 2; ++i) {
             const bool fresh = i >= imin;  // same for every thread
@@ -908,6 +911,10 @@ __device__ __forceinline__ void update_pre_body2(const UpdateArgs &a, double *s_
                 }
             }
         }
+        LMCMA_STAMP(14);
+#ifdef LMCMA_DIAG
+        if (threadIdx.x == 0) g_update_stamps[15] = (unsigned long long)((imin << 8) | isz);
+#endif
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             if (rebuild[q]) {
