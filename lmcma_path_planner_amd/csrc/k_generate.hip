@@ -49,7 +49,7 @@ __host__ __device__ constexpr int padded_row_floats(int D, int W) { return (D * 
 // 512-thread ones).
 __host__ __device__ constexpr int pre_emax_for(int J, int N)
 {
-    return J == 1 ? 8 : J == 2 ? (N <= 192 ? 12 : 16) : 0;
+    return J == 1 ? 8 : J == 2 ? (N <= 160 ? 10 : N <= 192 ? 12 : 16) : 0;
 }
 
 // J = float4 chunks per lane (row stride <= 128 J floats)
@@ -76,6 +76,7 @@ __device__ __forceinline__ void generate_body(const GenParams &g, const UpdateAr
         double *s_dyn = reinterpret_cast<double *>(smem);
         const UpdateArgs a = shifted(pre, blockIdx.y);
         if (J == 1) update_pre_body2<8>(a, s_dyn);
+        else if (J == 2 && a.N <= 160) update_pre_body2<10>(a, s_dyn);
         else if (J == 2 && a.N <= 192) update_pre_body2<12>(a, s_dyn);
         else if (J == 2) update_pre_body2<16>(a, s_dyn);
 #ifdef LMCMA_DIAG

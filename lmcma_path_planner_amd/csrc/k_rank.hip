@@ -558,14 +558,16 @@ hipError_t launch_rank_tp(hipStream_t s, const RankArgs &r, int blocks, size_t l
     return hipGetLastError();
 }
 
-// pre_emax: 0, or the register tile (8 / 16 / 32 coordinates per lane) of the update part riding along
+// pre_emax: 0, or the register tile (8 / 10 / 12 / 16 coordinates per lane) of the update part riding along
 template <int TB>
 hipError_t launch_rank_t(hipStream_t s, const RankArgs &r, int blocks, size_t lds, int pre_emax)
 {
     // the update part must fit the registers the workgroup size leaves per lane
     if (pre_emax == 8) return launch_rank_tp<TB, 8>(s, r, blocks, lds);
+    if (pre_emax == 10) return launch_rank_tp<TB, 10>(s, r, blocks, lds);
     if (pre_emax == 12) return launch_rank_tp<TB, 12>(s, r, blocks, lds);
     if (pre_emax == 16) return launch_rank_tp<TB, 16>(s, r, blocks, lds);
+    if (pre_emax != 0) return hipErrorInvalidValue;  // a tile this kernel has no variant for
     return launch_rank_tp<TB, 0>(s, r, blocks, lds);
 }
 

@@ -251,6 +251,7 @@ static hipError_t launch_post_t(hipStream_t s, const UpdateArgs &a)
 #define LMCMA_UPD_SPLIT(FN, TB)                              \
     do {                                                     \
         if (emax == 8) return FN<TB, 8>(s, a);               \
+        if (emax == 10) return FN<TB, 10>(s, a);             \
         if (emax == 12) return FN<TB, 12>(s, a);             \
         if (emax == 16) return FN<TB, 16>(s, a);             \
         if (emax == 20) return FN<TB, 20>(s, a);             \
@@ -287,6 +288,7 @@ hipError_t launch_update(hipStream_t s, const UpdateArgs &a)
 #define LMCMA_UPD(TB)                                          \
     do {                                                       \
         if (emax == 8) return launch_update_t<TB, 8, true>(s, a);   \
+        if (emax == 10) return launch_update_t<TB, 10, true>(s, a); \
         if (emax == 12) return launch_update_t<TB, 12, true>(s, a); \
         if (emax == 16) return launch_update_t<TB, 16, true>(s, a); \
         if (emax == 20) return launch_update_t<TB, 20, true>(s, a); \

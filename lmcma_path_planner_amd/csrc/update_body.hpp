@@ -217,7 +217,7 @@ static __device__ unsigned long long g_update_stamps[16];
 // (N <= 512): the register tile of the update kernels, and 1/16 of their LDS row stride
 __host__ __device__ constexpr int update_emax(int N)
 {
-    return N <= 128 ? 8 : N <= 192 ? 12 : N <= 256 ? 16 : N <= 320 ? 20 : N <= 384 ? 24 : 32;
+    return N <= 128 ? 8 : N <= 160 ? 10 : N <= 192 ? 12 : N <= 256 ? 16 : N <= 320 ? 20 : N <= 384 ? 24 : 32;
 }
 
 // LDS doubles the update needs for (N, m) when TR threads read the partial rows
