@@ -250,7 +250,7 @@ hipError_t launch_update(hipStream_t s, const UpdateArgs &a);
 // costs, then the rest.  update_is_split: the sizes the two-part kernels cover.
 bool update_is_split(int N, int m);
 // the first part is short enough to run as an extra workgroup of the ranking launch; otherwise it
-// gets a stream of its own beside the sampling and ranking launches
+// rides in the sampling launch (launch_generate) or stays in the single update kernel
 bool update_pre_rides_with_ranking(int m);
 int update_pre_threads(int m);  // threads of the first part that do vector work
 hipError_t launch_update_pre(hipStream_t s, const UpdateArgs &a);

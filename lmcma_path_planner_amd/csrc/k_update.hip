@@ -160,8 +160,8 @@ bool update_is_split(int N, int m)
     static const bool off = getenv("LMCMA_HIP_UPDATE_ONE_KERNEL") != nullptr;
     // Up to 32 vectors.  With up to 16 the first part rides in the ranking launch; with more it
     // (30 dependent steps at m = 32) outlasts that launch by more than the second part saves
-    // (measured 64.7 against 61.2 us per generation at lambda = 8192, N = 144, m = 32), so it runs
-    // on a stream of its own beside the sampling and ranking launches (update_pre_rides_with_ranking).
+    // (measured 64.7 against 61.2 us per generation at lambda = 8192, N = 144, m = 32), so it rides
+    // in the longer sampling launch instead (update_pre_rides_with_ranking, launch_generate).
     return !off && m >= 1 && threads_for_vectors(m) <= 512 && N >= 1 && N <= 512 && update_fits_lds(N, m);
 }
 
