@@ -481,7 +481,7 @@ int do_recombine(lmcma_hip_ctx *c)
 {
     Timed tm(c, LMCMA_K_RECOMBINE);
     HIP_TRY(launch_recombine(c->stream, c->rows, c->ld, c->N, c->first, c->nloc, c->perm, c->weights,
-                             c->mu, c->block_partials));
+                             c->mu, c->block_partials, batch_of(c)));
     return LMCMA_HIP_OK;
 }
 
@@ -1361,8 +1361,12 @@ int lmcma_hip_phase_rank(lmcma_hip_ctx *c)
     if (rc != LMCMA_HIP_OK) return rc;
     if (c->Q > 1) {
         // several queries: nothing leaves the context, the update adds the block rows itself
+        if (rows == 0) {  // many queries are ranked one workgroup each; their elite rows are added here
+            if ((rc = do_recombine(c)) != LMCMA_HIP_OK) return rc;
+            rows = recombine_num_blocks(c->mu);
+        }
         c->pending_rows = rows;
-        return rows > 0 ? LMCMA_HIP_OK : fail(LMCMA_HIP_ERR_STATE, "phase_rank: the ranking launch left no partial rows");
+        return LMCMA_HIP_OK;
     }
     if (rows > 0) return do_recombine_final(c, rows, true);
     rc = do_recombine(c);

@@ -196,7 +196,7 @@ constexpr int kRecombineRanksPerBlock = 32;
 int recombine_num_blocks(int mu);
 hipError_t launch_recombine(hipStream_t s, const float *rows, int ld, int N, int first_candidate,
                             int n_local, const int32_t *perm, const double *weights, int mu,
-                            double *block_partials);
+                            double *block_partials, Batch batch = Batch{1, 0});
 
 // partial_local[N] = sum of the first `rows` rows of block_partials, in the order in which a
 // workgroup of `threads` threads adds them (the update adds its partial rows in the same

@@ -340,6 +340,309 @@ __global__ __launch_bounds__(TB) void k_rank(const RankArgs r_in)
 #endif
 }
 
+// ---- one workgroup ranks one whole population: a sample sort ------------------------------
+// Counting costs lambda^2 compares per population: fine when one population has the chip to
+// itself (k_rank: a microsecond or two on every CU), wasteful when many populations are ranked
+// by one launch (several queries in one context), where all that matters is the CU time a
+// population takes.  Here 512 threads rank up to 4096 keys with some lambda (9 + lambda / 256)
+// compares: 512 keys sampled at a fixed stride are ranked among themselves, the 511 lowest
+// split the key space into 512 buckets; every key finds its bucket by binary search and takes a
+// place in it (LDS counter); inside a bucket, 16 lanes count for every member the members below
+// it.  rank = start of the bucket + that count.  Keys are the 64-bit words (order-preserving
+// image of the cost << 32) | candidate index, all distinct, so equal costs rank in candidate
+// order and equal costs cannot crowd one bucket.  The success-rule count is a binary search of
+// every cost in last generation's list (staged in LDS).  The elite rows are not added here.
+constexpr int kSortedThreads = 512;
+constexpr int kSortedMax = 4096;      // 8 keys per thread
+constexpr int kSortedBuckets = 512;
+
+typedef double SortKey;
+__device__ __forceinline__ SortKey sort_key(uint32_t bits, uint32_t index) { return (double)bits * 4096.0 + (double)index; }
+
+size_t rank_sorted_lds_bytes(bool psr)
+{
+    return (size_t)kSortedMax * (sizeof(SortKey) + sizeof(int) + sizeof(uint16_t)) + (2 * kSortedBuckets + 8) * sizeof(SortKey) +
+           2 * kSortedBuckets * sizeof(int) + 16 * sizeof(uint32_t) + (psr ? kSortedMax * sizeof(float) : 0);
+}
+
+template <int PRE_EMAX>
+__global__ __launch_bounds__(kSortedThreads) void k_rank_sorted(const RankArgs r_in)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+    if (PRE_EMAX > 0) {
+        if (blockIdx.x == 1) {  // the first part of this query's update, beside its ranking
+            update_pre_body<(PRE_EMAX > 0 ? PRE_EMAX : 8)>(shifted(r_in.pre, blockIdx.y), s_dyn, r_in.pre_threads);
+            return;
+        }
+    }
+    RankArgs r = r_in;
+    if (r.batch.stride != 0) {
+        const size_t off = (size_t)blockIdx.y * r.batch.stride;
+        shift_ptr(r.cost, off); shift_ptr(r.sorted_cost, off); shift_ptr(r.perm, off); shift_ptr(r.opt, off);
+        shift_ptr(r.prev_sorted, off); shift_ptr(r.psr_parts, off);
+    }
+    constexpr int TB = kSortedThreads, KPT = kSortedMax / kSortedThreads, NB = kSortedBuckets;
+    static_assert(NB == TB, "one sample, one bucket per thread");
+    const int tid = threadIdx.x;
+    const int lambda = r.lambda;
+    const bool psr = r.prev_sorted != nullptr && r.opt != nullptr && r.opt->itr > 0;
+
+    // A key is the integer (order-preserving image of the cost) * 4096 + candidate index, below
+    // 2^44, held as a double: exact, and compared by the fp64 compare instead of a 64-bit integer one.
+    SortKey *s_grp = reinterpret_cast<SortKey *>(s_dyn);        // [4096 + 8] keys grouped by bucket, then +inf
+    SortKey *s_samp = s_grp + kSortedMax + 8;                   // [NB] the sampled keys
+    SortKey *s_split = s_samp + NB;                             // [NB] ... in ascending order
+    int *s_rank = reinterpret_cast<int *>(s_split + NB);        // [4096] rank of the key at a grouped position
+    int *s_hist = s_rank + kSortedMax;                          // [NB] members per bucket
+    int *s_start = s_hist + NB;                                 // [NB] first grouped position of a bucket
+    uint16_t *s_bkt = reinterpret_cast<uint16_t *>(s_start + NB);  // [4096] bucket of a grouped position
+    uint32_t *s_below = reinterpret_cast<uint32_t *>(s_bkt + kSortedMax);  // [TB / 64]
+    float *s_prev = reinterpret_cast<float *>(s_below + 16);    // [4096] when psr
+
+#ifdef LMCMA_DIAG
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    RANK_STAMP(0);
+    // ---- loads: this thread's keys (candidates tid, tid + 512, ...) and last generation's list
+    float c[KPT];
+#pragma unroll
+    for (int e = 0; e < KPT; ++e) {
+        const int i = tid + e * TB;
+        c[e] = r.cost[i < lambda ? i : lambda - 1];
+    }
+    if (psr) {
+        const int n4 = lambda >> 2;  // lambda is a multiple of 512
+        float4 pv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = tid + u * TB;
+            pv[u] = reinterpret_cast<const float4 *>(r.prev_sorted)[t < n4 ? t : n4 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = tid + u * TB;
+            if (t < n4) reinterpret_cast<float4 *>(s_prev)[t] = pv[u];
+        }
+    }
+    s_hist[tid] = 0;
+    if (tid < 8) s_grp[lambda + tid] = 1.7976931348623157e308;
+    SortKey key[KPT];
+    const int stride = lambda / NB;  // NB samples
+#pragma unroll
+    for (int e = 0; e < KPT; ++e) {
+        const int i = tid + e * TB;
+        key[e] = sort_key(order_bits(c[e]), (uint32_t)i);
+    }
+    // sample j is candidate j * stride + stride / 2
+#pragma unroll
+    for (int e = 0; e < KPT; ++e) {
+        const int i = tid + e * TB;
+        // (stride is a power of two or not: i - stride / 2 divisible by stride)
+        const int q = (i - (stride >> 1)) / stride;
+        if (i < lambda && q * stride + (stride >> 1) == i) s_samp[q] = key[e];
+    }
+    __syncthreads();
+    RANK_STAMP(1);
+
+    // ---- the samples in ascending order.  Every wave sorts its 64 (a bitonic network over the
+    // lanes, 21 exchanges), then every sample adds its positions in the other waves' sorted runs
+    // (binary searches) to its position in its own: its rank among all of them.
+    {
+        SortKey mine = s_samp[tid];
+        const int ln = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+            for (int strd = size >> 1; strd > 0; strd >>= 1) {
+                const SortKey o = __shfl_xor(mine, strd, 64);
+                const bool keep_min = ((ln & size) == 0) == ((ln & strd) == 0);
+                mine = keep_min ? fmin(mine, o) : fmax(mine, o);
+            }
+        }
+        __syncthreads();  // every thread has read its sample
+        s_samp[tid] = mine;  // run wv, position ln
+        __syncthreads();
+        constexpr int NW = TB / 64;
+        int cnt[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) cnt[w] = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+            SortKey o[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) o[w] = s_samp[64 * w + cnt[w] + step - 1];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int w = 0; w < NW; ++w) cnt[w] += (o[w] < mine) ? step : 0;
+        }
+        // (five steps reach 63 of a run's 64; the last entry of each run is compared on its own)
+        int below = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const SortKey last = s_samp[64 * w + 63];
+            const int c = cnt[w] + ((cnt[w] == 63 && last < mine) ? 1 : 0);
+            below += (w == wv) ? ln : c;
+        }
+        s_split[below] = mine;
+    }
+    __syncthreads();
+    RANK_STAMP(2);
+
+    // ---- bucket of every key = number of the NB - 1 lowest samples below it; a place in the bucket
+    int place[KPT];
+    {
+        int cnt[KPT];
+#pragma unroll
+        for (int e = 0; e < KPT; ++e) cnt[e] = 0;
+#pragma unroll
+        for (int step = NB >> 1; step > 0; step >>= 1) {
+            SortKey sp[KPT];
+#pragma unroll
+            for (int e = 0; e < KPT; ++e) sp[e] = s_split[cnt[e] + step - 1];
+            asm volatile("" ::: "memory");  // the eight reads are in flight together
+#pragma unroll
+            for (int e = 0; e < KPT; ++e) cnt[e] += (sp[e] < key[e]) ? step : 0;
+        }
+#pragma unroll
+        for (int e = 0; e < KPT; ++e) {
+            place[e] = 0;
+            if (tid + e * TB < lambda) place[e] = (cnt[e] << 16) | atomicAdd(&s_hist[cnt[e]], 1);
+        }
+    }
+    __syncthreads();
+    RANK_STAMP(3);
+    if (tid < 64) {
+        // exclusive prefix over the bucket sizes, NB / 64 consecutive ones per lane
+        constexpr int PL = NB / 64;
+        int cn[PL], sum = 0;
+#pragma unroll
+        for (int u = 0; u < PL; ++u) {
+            cn[u] = s_hist[PL * tid + u];
+            sum += cn[u];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const int o = __shfl_up(incl, sft, 64);
+            if (tid >= sft) incl += o;
+        }
+        int at = incl - sum;
+#pragma unroll
+        for (int u = 0; u < PL; ++u) {
+            s_start[PL * tid + u] = at;
+            at += cn[u];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < KPT; ++e) {
+        if (tid + e * TB < lambda) {
+            const int b = place[e] >> 16;
+            place[e] = s_start[b] + (place[e] & 0xFFFF);
+            s_grp[place[e]] = key[e];
+            s_bkt[place[e]] = (uint16_t)b;
+        }
+    }
+    __syncthreads();
+    RANK_STAMP(4);
+
+    // ---- ranks inside the buckets.  A thread takes grouped positions tid, tid + 512, ...: the
+    // lanes of a wave hold neighbouring positions, so they walk through a handful of buckets
+    // and one LDS word serves many lanes.
+#pragma unroll 1
+    for (int e = 0; e < KPT; ++e) {
+        const int p = tid + e * TB;
+        if (p < lambda) {
+            const int b = s_bkt[p];
+            const int base = s_start[b], n = s_hist[b];
+            const SortKey mine = s_grp[p];
+            // whole batches of eight reads: what follows a bucket in the grouped array are the later
+            // buckets' keys (and eight entries of +inf after the last), none of them below this key
+            int below = 0;
+            for (int k = 0; k < n; k += 8) {
+                SortKey o[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o[u] = s_grp[base + k + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) below += o[u] < mine;
+            }
+            s_rank[p] = base + below;
+        }
+    }
+    __syncthreads();
+    RANK_STAMP(5);
+
+    // ---- the sorted list in LDS (over the grouped keys, which are done with): every key to its rank
+    float *s_val = reinterpret_cast<float *>(s_grp);            // [4096] costs in ascending order
+    int *s_idx = reinterpret_cast<int *>(s_val + kSortedMax);   // [4096] their candidates
+#pragma unroll
+    for (int e = 0; e < KPT; ++e) {
+        const int i = tid + e * TB;
+        if (i < lambda) {
+            const int rank = s_rank[place[e]];
+            s_val[rank] = order_bits_inv(order_bits(c[e]));
+            s_idx[rank] = i;
+        }
+    }
+    __syncthreads();
+    RANK_STAMP(6);
+    // out in whole lines: thread t writes ranks 8 t .. 8 t + 7
+    if (KPT * tid < lambda) {
+        const float4 v0 = reinterpret_cast<const float4 *>(s_val)[2 * tid], v1 = reinterpret_cast<const float4 *>(s_val)[2 * tid + 1];
+        const int4 i0 = reinterpret_cast<const int4 *>(s_idx)[2 * tid], i1 = reinterpret_cast<const int4 *>(s_idx)[2 * tid + 1];
+        reinterpret_cast<float4 *>(r.sorted_cost)[2 * tid] = v0;
+        reinterpret_cast<float4 *>(r.sorted_cost)[2 * tid + 1] = v1;
+        reinterpret_cast<int4 *>(r.perm)[2 * tid] = i0;
+        reinterpret_cast<int4 *>(r.perm)[2 * tid + 1] = i1;
+    }
+
+    // ---- success rule: the number of pairs (cost of last generation, cost of this one) with the
+    // former below the latter, by merging the two ascending lists: thread t merges elements
+    // [t per, (t + 1) per) of the merged order (a current cost goes before an equal previous one)
+    // and adds, for every current cost it takes, the previous costs already taken.
+    uint32_t below_prev = 0;
+    if (psr) {
+        const int per = (2 * lambda) / TB, d = tid * per;
+        int lo = d > lambda ? d - lambda : 0, hi = d < lambda ? d : lambda;
+        while (__any(lo < hi)) {
+            const bool act = lo < hi;
+            const int mid = act ? (lo + hi) >> 1 : 0;
+            const int jb = act ? d - mid - 1 : 0;
+            const float a = s_val[mid], b = s_prev[jb];
+            if (act) {
+                if (a <= b) lo = mid + 1;
+                else hi = mid;
+            }
+        }
+        int ia = lo, jb = d - lo;
+        float a = s_val[ia < lambda ? ia : lambda - 1], b = s_prev[jb < lambda ? jb : lambda - 1];
+        for (int t = 0; t < per; ++t) {
+            const bool take_a = jb >= lambda || (ia < lambda && a <= b);
+            below_prev += take_a ? (uint32_t)jb : 0u;
+            ia += take_a ? 1 : 0;
+            jb += take_a ? 0 : 1;
+            const float na = s_val[ia < lambda ? ia : lambda - 1], nb = s_prev[jb < lambda ? jb : lambda - 1];
+            a = na;
+            b = nb;
+        }
+    }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) below_prev += __shfl_xor(below_prev, sft, 64);
+    if ((tid & 63) == 0) s_below[tid >> 6] = below_prev;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < TB / 64; ++w) total += s_below[w];
+        r.psr_parts[0] = total;
+    }
+#ifdef LMCMA_DIAG
+    RANK_STAMP(7);
+    if (tid == 0 && blockIdx.y == 0)
+        for (int q = 0; q < 8; ++q) g_update_stamps[8 + q] = st[q];
+#endif
+}
+
 // ---- one shard of a population: global ranks of the local candidates by merging ----------
 // In a job of G contexts each context first ranks its own n_local candidates among
 // themselves (k_rank on the local costs) and puts its ASCENDING costs into its block of the
@@ -665,6 +968,47 @@ hipError_t launch_select(hipStream_t s, const SelectArgs &a, SelectResult *res)
     const OptScalars *opt = (a.prev_sorted && a.psr_accum) ? a.opt : nullptr;
     RankArgs r{};
     r.batch = a.batch.queries >= 1 ? a.batch : Batch{1, 0};
+    // Many populations in one launch: one workgroup each (k_rank_sorted) instead of lambda / 32.
+    // From 16 queries on the launch is shorter that way (one query: 8.6 us by counting on every CU
+    // against some 15 us for the single workgroup and the recombination launch it needs).
+    static const int sorted_from = getenv("LMCMA_HIP_SORTED_RANK_FROM") ? atoi(getenv("LMCMA_HIP_SORTED_RANK_FROM")) : 16;
+    if (a.tile_len == 0 && r.batch.queries >= sorted_from && lambda >= 1024 && lambda <= kSortedMax && lambda % kSortedBuckets == 0) {
+        r.cost = a.cost_all;
+        r.lambda = lambda;
+        r.sorted_cost = a.sorted_cost;
+        r.perm = a.perm;
+        r.opt = opt;
+        r.prev_sorted = opt ? a.prev_sorted : nullptr;
+        r.psr_parts = reinterpret_cast<uint32_t *>(a.keys_ws);
+        size_t lds = rank_sorted_lds_bytes(opt != nullptr);
+        int pre_emax = 0;
+        if (a.pre && update_is_split(a.pre->N, a.pre->m) && update_pre_rides_with_ranking(a.pre->m) &&
+            update_pre_threads(a.pre->m) <= kSortedThreads && a.pre->N <= 256) {
+            r.pre = *a.pre;
+            r.pre_threads = update_pre_threads(a.pre->m);
+            pre_emax = update_emax(a.pre->N);
+            lds = std::max(lds, update_pre_lds_doubles(a.pre->N, a.pre->m) * sizeof(double));
+        }
+        const dim3 grid(pre_emax > 0 ? 2 : 1, r.batch.queries);
+#define LMCMA_SORTED(E)                                                                                     \
+    do {                                                                                                    \
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_rank_sorted<E>), lds);          \
+        if (e != hipSuccess) return e;                                                                      \
+        hipLaunchKernelGGL((k_rank_sorted<E>), grid, dim3(kSortedThreads), lds, s, r);                      \
+    } while (0)
+        if (pre_emax == 8) LMCMA_SORTED(8);
+        else if (pre_emax == 10) LMCMA_SORTED(10);
+        else if (pre_emax == 12) LMCMA_SORTED(12);
+        else if (pre_emax == 16) LMCMA_SORTED(16);
+        else if (pre_emax == 0) LMCMA_SORTED(0);
+        else return hipErrorInvalidValue;
+#undef LMCMA_SORTED
+        out.partial_rows = 0;  // the elite rows are added by launch_recombine
+        out.pre_done = pre_emax > 0;
+        out.psr_parts = opt ? 1 : 0;
+        if (res) *res = out;
+        return hipGetLastError();
+    }
     r.tile_len = a.tile_len;
     r.cost = a.cost_all;
     r.lambda = lambda;

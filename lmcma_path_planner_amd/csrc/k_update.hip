@@ -17,13 +17,17 @@ namespace {
 // The slots are then added in slot order through LDS, and k_update (or
 // k_recombine_final) adds the blocks in block order: the summation tree is fixed
 // by (mu, ld) alone.  Rows that live in another context are skipped.
-__global__ __launch_bounds__(256) void k_recombine_partial(const float *__restrict__ rows, int ld,
+__global__ __launch_bounds__(256) void k_recombine_partial(const float *rows, int ld,
                                                            int N, int first_candidate, int n_local,
-                                                           const int32_t *__restrict__ perm,
-                                                           const double *__restrict__ weights,
-                                                           int mu, double *__restrict__ block_partials)
+                                                           const int32_t *perm,
+                                                           const double *weights,
+                                                           int mu, double *block_partials, size_t qstride)
 {
     extern __shared__ __attribute__((aligned(16))) double s_part[];  // [nslots][ld]
+    if (qstride != 0) {  // query blockIdx.y of a batch
+        const size_t off = (size_t)blockIdx.y * qstride;
+        shift_ptr(rows, off); shift_ptr(perm, off); shift_ptr(weights, off); shift_ptr(block_partials, off);
+    }
     const int nq = ld >> 2;               // float4 chunks per row (<= 128)
     const int nslots = 256 / nq;
     const int r0 = blockIdx.x * kRecombineRanksPerBlock;
@@ -176,14 +180,14 @@ int recombine_num_blocks(int mu)
 
 hipError_t launch_recombine(hipStream_t s, const float *rows, int ld, int N, int first_candidate,
                             int n_local, const int32_t *perm, const double *weights, int mu,
-                            double *block_partials)
+                            double *block_partials, Batch batch)
 {
-    if (mu <= 0 || N <= 0 || (ld & 3) || ld > 512) return hipErrorInvalidValue;
+    if (mu <= 0 || N <= 0 || (ld & 3) || ld > 512 || batch.queries < 1) return hipErrorInvalidValue;
     const int nb = recombine_num_blocks(mu);
     const int nslots = 256 / (ld >> 2);
     const size_t lds = (size_t)nslots * ld * sizeof(double);
-    hipLaunchKernelGGL(k_recombine_partial, dim3(nb), dim3(256), lds, s, rows, ld, N, first_candidate,
-                       n_local, perm, weights, mu, block_partials);
+    hipLaunchKernelGGL(k_recombine_partial, dim3(nb, batch.queries), dim3(256), lds, s, rows, ld, N, first_candidate,
+                       n_local, perm, weights, mu, block_partials, batch.stride);
     return hipGetLastError();
 }
 

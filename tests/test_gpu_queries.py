@@ -153,3 +153,84 @@ def test_queries_argument_checks():
     with pytest.raises(LmcmaError, match="not a shard"):
         ctx.phase_update(2)
     ctx.close()
+
+
+@pytest.mark.parametrize("lam,mode,gens", [(4096, "random", 20), (2048, "random", 6), (1024, "ties", 4), (4096, "ties", 3)])
+def test_many_queries_are_ranked_one_workgroup_each(oracle, lam, mode, gens):
+    """From 16 queries on, every population of a context is ranked by one workgroup (a sample sort)
+    and its elite rows are added by the rank-ordered recombination launch.  Checked per generation
+    for three of the queries: the permutation and the sorted costs are those of a stable sort of the
+    query's costs ("ties": degenerate bounds make all costs equal, so the order is the candidate
+    order), and the state follows the CPU oracle handed the same rows and costs.  The replayed
+    loop of a second context makes the same run bit for bit, and a one-query context (ranked by
+    counting, another order of the same fp64 sums) agrees to rounding."""
+    import torch
+    from lmcma_path_planner_amd import dist as shard_mod
+    from lmcma_path_planner_amd import grids, hip
+    prob = grids.benchmark_problem(2)
+    Q, m, seed = 16, 16, 31
+    dev = torch.device("cuda", 0)
+    lo, hi = (prob.x0, prob.x0) if mode == "ties" else (prob.lo, prob.hi)
+
+    def make(queries, s):
+        c = hip.HipContext(prob.N, lam, m, dims=prob.dims, waypoints=prob.W, start=prob.start, goal=prob.goal, seed=s,
+                           queries=queries)
+        c.set_grid(prob.occ)
+        c.set_bounds(lo, hi)
+        c.opt_init(prob.x0, prob.sigma0)
+        return c
+
+    ctx = make(Q, seed)
+    watch = (0, 7, 15)
+    os_ = {q: oracle.OracleLMCMA(prob.N, lam, m, initial=prob.x0, lo=lo, hi=hi, sigma=prob.sigma0, seed=seed + q,
+                                 z_source=oracle.Z_GIVEN) for q in watch}
+    for g in range(gens):
+        ctx.phase_local()
+        got = {}
+        for q in watch:
+            ctx.query_select(q)
+            got[q] = (ctx.rows(), ctx.costs())
+        ctx.phase_rank()
+        ctx.synchronize()
+        for q in watch:
+            ctx.query_select(q)
+            raw = got[q][1].astype(np.float32)
+            order = np.argsort(raw.astype(np.float64), kind="stable")
+            perm = shard_mod.alias_tensor(ctx, hip.BUF_PERM, torch.int32, dev).cpu().numpy()
+            sc = shard_mod.alias_tensor(ctx, hip.BUF_SORTED_COST, torch.float32, dev).cpu().numpy()
+            np.testing.assert_array_equal(perm, order)
+            np.testing.assert_array_equal(sc, raw[order])
+            if mode == "ties":
+                assert np.all(raw == raw[0])
+        ctx.phase_update(0)
+        for q in watch:
+            ctx.query_select(q)
+            o = os_[q]
+            o.set_arx(got[q][0])
+            o.update_only(got[q][1])
+            st, vec = ctx.opt_get(), ctx.opt_vectors()
+            assert st["itr"] == o.itr == g + 1 and st["iterator_sz"] == o.iterator_sz
+            np.testing.assert_allclose(st["xmean"], o.xmean, rtol=1e-11, atol=1e-11)
+            np.testing.assert_allclose(st["sigma"], o.sigma, rtol=1e-11)
+            assert st["best_f"] == o.BestF and st["counteval"] == o.counteval
+            live = o.iterator[: o.iterator_sz]
+            np.testing.assert_allclose(vec["v_arr"][live], o.v_arr[live], rtol=1e-8, atol=1e-10)
+    # the replayed loop: same launches, same bits
+    again = make(Q, seed)
+    again.run(gens)
+    for q in watch:
+        ctx.query_select(q)
+        again.query_select(q)
+        a, b = ctx.opt_get(), again.opt_get()
+        np.testing.assert_array_equal(a["xmean"], b["xmean"])
+        assert a["sigma"] == b["sigma"] and a["itr"] == b["itr"] == gens
+    # a context of its own per query ranks by counting: the same run up to the order of the fp64 sums
+    one = make(1, seed + 7)
+    one.run(gens)
+    ctx.query_select(7)
+    a, b = ctx.opt_get(), one.opt_get()
+    np.testing.assert_allclose(a["xmean"], b["xmean"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(a["sigma"], b["sigma"], rtol=1e-9)
+    assert a["best_f"] == b["best_f"]
+    for c in (ctx, again, one):
+        c.close()
