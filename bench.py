@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--queries", type=int, default=1,
                     help="independent optimisers (restarts of the planning problem, own seeds) advanced together by "
                     "every launch of one context; 1 = the configuration as named")
-    ap.add_argument("--batched-queries", type=int, default=16,
+    ap.add_argument("--batched-queries", type=int, default=64,
                     help="after the headline measurement, also measure this many queries in one context (0: skip)")
     ap.add_argument("--structured-covariance", action="store_true",
                     help="sample with the smoothness covariance of the reference (z <- L z on the matrix cores); "

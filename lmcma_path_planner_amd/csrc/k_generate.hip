@@ -401,6 +401,208 @@ __global__ __launch_bounds__(TB) void k_generate_pre(const GenParams g, const Up
     generate_body<J, D, false, VB_LDS, false, true, TB>(g, pre);
 }
 
+// ---- many queries per launch: the two products on the matrix cores ---------------------------
+// With one query the sampling kernel waits for memory most of its time; with many queries in
+// one launch it is bound by vector-instruction issue, and over half of its vector instructions
+// are the two products of computeAz (L/lmcma.cpp:431-447 in closed form): D = V z (m dot
+// products per candidate, reduced over lanes) and x = M^k z + sum_t d_t B_t.  Over a tile of
+// candidates they are two small dense matrix products, and here they run as
+// v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: no precision given up, only the order of
+// the sums changes):
+//   a wave owns 16 candidates; lane (c = l % 16, q = l / 16) draws the chunks q, q + 4, ..., q + 28
+//   of candidate c's normals (the same Philox counters as everywhere else);
+//   D^T [t][c] = sum_n V[t][n] z[c][n]: A = V from LDS, B = the lane's own normals, 32 steps;
+//   X^T [n][c] = M^k z[c][n] + sum_t B[t][n] D^T[t][c]: per 16 rows n, C starts as M^k z, A = B
+//   from LDS, B = D^T as the first product left it in registers (K index t = 4 (l / 16) + step),
+//   and the result lands chunk for chunk in the lane that drew that chunk.
+// The scoring half is the one of generate_body, 32 lanes per candidate, eight candidates per pass.
+// Rows of up to 128 floats, up to 32 direction vectors.
+constexpr int kMfmaLD = 132;    // LDS stride of a direction vector: 16-byte aligned, rows four banks apart
+constexpr int kMfmaTile = 64;   // candidates per workgroup pass (four waves)
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+size_t generate_mfma_lds_bytes(int D, int W, int m)
+{
+    const int mp = (m + 15) & ~15;
+    return ((size_t)kMfmaTile * padded_row_floats(D, W) + 2 * (size_t)mp * kMfmaLD + 3 * 128) * sizeof(float);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_generate_mfma(const GenParams g)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int block = (int)blockIdx.x, nblocks = (int)gridDim.x;
+    const size_t qoff = (size_t)blockIdx.y * g.batch.stride;
+    float *q_rows = g.rows, *q_cost = g.cost.cost, *q_terms = g.cost.terms;
+    const float *q_xmean = g.xmean, *q_V = g.V, *q_B = g.B, *q_lo = g.lo, *q_hi = g.hi;
+    const SampleScalars *q_sc = g.sc;
+    shift_ptr(q_rows, qoff); shift_ptr(q_cost, qoff); shift_ptr(q_terms, qoff); shift_ptr(q_xmean, qoff);
+    shift_ptr(q_V, qoff); shift_ptr(q_B, qoff); shift_ptr(q_lo, qoff); shift_ptr(q_hi, qoff); shift_ptr(q_sc, qoff);
+    const uint32_t q_key0 = g.key0 + blockIdx.y;
+    const CostParams &p = g.cost;
+    const int ld = g.ld, nchunks = ld >> 2;
+    const int k = q_sc->k;
+    const float sigma = q_sc->sigma, mk = q_sc->mk;
+    const uint32_t generation = q_sc->generation;
+    const int mp = (g.m + 15) & ~15;
+    const int LP = padded_row_floats(D, p.W);
+    float *srows = smem;                        // [64][LP]
+    float *sV = srows + kMfmaTile * LP;         // [mp][132], zero beyond the row and from vector k on
+    float *sB = sV + mp * kMfmaLD;              // [mp][132]
+    float *s_mean = sB + mp * kMfmaLD;          // [128] mean, [128] lower, [128] upper bounds
+    const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6, c16 = l & 15, q = l >> 4;
+
+    // ---- staging (every load requested before the first LDS store)
+    {
+        float4 mv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < 96) {
+            const int which = tid >> 5, chunk = tid & 31;
+            const float *src = which == 0 ? q_xmean : which == 1 ? q_lo : q_hi;
+            mv = reinterpret_cast<const float4 *>(src)[chunk < nchunks ? chunk : nchunks - 1];
+            if (chunk >= nchunks) mv = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 tv[4], tb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u, row = i >> 5, chunk = i & 31;
+            const bool real = i < mp * 32 && row < g.m && chunk < nchunks;
+            const int at = real ? row * nchunks + chunk : 0;
+            tv[u] = reinterpret_cast<const float4 *>(q_V)[at];
+            tb[u] = reinterpret_cast<const float4 *>(q_B)[at];
+        }
+        asm volatile("" ::: "memory");
+        if (tid < 96) reinterpret_cast<float4 *>(s_mean)[tid] = mv;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u, row = i >> 5, chunk = i & 31;
+            if (i < mp * 32) {
+                const bool real = row < g.m && row < k && chunk < nchunks;
+                const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(sV + row * kMfmaLD + 4 * chunk) = real ? tv[u] : zero;
+                *reinterpret_cast<float4 *>(sB + row * kMfmaLD + 4 * chunk) = real ? tb[u] : zero;
+            }
+        }
+        // the fixed end points around every dimension of every row of the tile
+        for (int i = tid; i < kMfmaTile * D * 4; i += 256) {
+            const int e = i & 3, d = (i >> 2) % D, sl = i / (4 * D);
+            srows[sl * LP + d * (p.W + 4) + (e < 2 ? e : p.W + e)] = e < 2 ? p.start[d] : p.goal[d];
+        }
+    }
+    const uint32_t *bits = reinterpret_cast<const uint32_t *>(p.grid);
+    const int ntiles = (g.n_local + kMfmaTile - 1) / kMfmaTile;
+
+    for (int tile = block; tile < ntiles; tile += nblocks) {
+        const int slot = wave * 16 + c16;
+        const int cand = tile * kMfmaTile + slot;
+        const bool live = cand < g.n_local;
+        const int c = live ? cand : g.n_local - 1;
+
+        // ---- the lane's normals: chunks q, q + 4, ..., q + 28 of candidate c
+        float4 z[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int chunk = q + 4 * j;
+            z[j] = chunk < nchunks ? philox_normals((uint32_t)chunk, g.first_candidate + (uint32_t)c, generation, q_key0, g.key1)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();  // staging done (first pass) / the previous tile's rows have been scored
+
+        // ---- D^T = V Z^T
+        v4f dT0 = {0.f, 0.f, 0.f, 0.f}, dT1 = {0.f, 0.f, 0.f, 0.f};
+        if (k > 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 va = *reinterpret_cast<const float4 *>(sV + c16 * kMfmaLD + 4 * (q + 4 * j));
+                dT0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, z[j].x, dT0, 0, 0, 0);
+                dT0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, z[j].y, dT0, 0, 0, 0);
+                dT0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, z[j].z, dT0, 0, 0, 0);
+                dT0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va.w, z[j].w, dT0, 0, 0, 0);
+            }
+            if (k > 16) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 va = *reinterpret_cast<const float4 *>(sV + (16 + c16) * kMfmaLD + 4 * (q + 4 * j));
+                    dT1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, z[j].x, dT1, 0, 0, 0);
+                    dT1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, z[j].y, dT1, 0, 0, 0);
+                    dT1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, z[j].z, dT1, 0, 0, 0);
+                    dT1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va.w, z[j].w, dT1, 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- X^T = M^k Z^T + B^T D^T, sixteen rows (four chunks of the row) at a time; clamp; out
+        float *lrow = srows + slot * LP;
+        float4 *out = reinterpret_cast<float4 *>(q_rows + (size_t)c * ld);
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            v4f x = {mk * z[nt].x, mk * z[nt].y, mk * z[nt].z, mk * z[nt].w};
+            if (k > 0) {
+                const float *b0 = sB + (4 * q) * kMfmaLD + 16 * nt + c16;
+                x = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[0], dT0[0], x, 0, 0, 0);
+                x = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[kMfmaLD], dT0[1], x, 0, 0, 0);
+                x = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[2 * kMfmaLD], dT0[2], x, 0, 0, 0);
+                x = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[3 * kMfmaLD], dT0[3], x, 0, 0, 0);
+                if (k > 16) {
+                    const float *b1 = b0 + 16 * kMfmaLD;
+                    x = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[0], dT1[0], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[kMfmaLD], dT1[1], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[2 * kMfmaLD], dT1[2], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[3 * kMfmaLD], dT1[3], x, 0, 0, 0);
+                }
+            }
+            const int chunk = 4 * nt + q;
+            if (chunk < nchunks) {
+                const float4 xm = reinterpret_cast<const float4 *>(s_mean)[chunk];
+                const float4 lo = reinterpret_cast<const float4 *>(s_mean + 128)[chunk];
+                const float4 hi = reinterpret_cast<const float4 *>(s_mean + 256)[chunk];
+                float4 r;
+                // max with the lower bound first, then min with the upper one (lmcma.cpp:222-229)
+                r.x = fminf(fmaxf(fmaf(sigma, x[0], xm.x), lo.x), hi.x);
+                r.y = fminf(fmaxf(fmaf(sigma, x[1], xm.y), lo.y), hi.y);
+                r.z = fminf(fmaxf(fmaf(sigma, x[2], xm.z), lo.z), hi.z);
+                r.w = fminf(fmaxf(fmaf(sigma, x[3], xm.w), lo.w), hi.w);
+                const float re[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = 4 * chunk + e;
+                    const int d = (D > 1 && n >= p.W ? 1 : 0) + (D > 2 && n >= 2 * p.W ? 1 : 0);
+                    if (n < D * p.W) lrow[n + 4 * d + 2] = re[e];
+                }
+                if (live) out[chunk] = r;
+            }
+        }
+        __syncthreads();  // the tile's rows are complete in LDS
+
+        // ---- score: 32 lanes per candidate, eight candidates per pass
+        const int lane = tid & 31;
+        for (int pass = 0; pass < kMfmaTile / 8; ++pass) {
+            const int sl = pass * 8 + (tid >> 5), sc_cand = tile * kMfmaTile + sl;
+            float j_len = 0.f, j_grid = 0.f, j_smooth = 0.f;
+            const float *row = srows + sl * LP;
+            for (int w0 = lane; w0 < p.W; w0 += 2 * kLanes) {
+                const int w1 = w0 + kLanes;
+                const bool has1 = w1 < p.W;
+                const WaypointPart a = waypoint_prepare_padded<D>(p, row, w0);
+                const WaypointPart b = waypoint_prepare_padded<D>(p, row, has1 ? w1 : w0);
+                const float ca = grid_value_at(p, bits, a.cell);
+                const float cb = grid_value_at(p, bits, b.cell);
+                waypoint_finish(p, a, w0, ca, j_len, j_grid, j_smooth);
+                if (has1) waypoint_finish(p, b, w1, cb, j_len, j_grid, j_smooth);
+            }
+            j_len = group_sum<kLanes>(j_len);
+            j_grid = group_sum<kLanes>(j_grid);
+            j_smooth = group_sum<kLanes>(j_smooth);
+            if (sc_cand < g.n_local && lane == 0) {
+                q_cost[sc_cand] = total_cost(p, j_len, j_grid, j_smooth);
+                if (q_terms) {
+                    float *t = q_terms + 3 * (size_t)sc_cand;
+                    t[0] = j_len; t[1] = j_grid; t[2] = j_smooth;
+                }
+            }
+        }
+    }
+}
+
 template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV, bool PRE, int TB = 256>
 hipError_t launch_t(hipStream_t s, const GenParams &g, size_t lds, int blocks, const UpdateArgs *pre)
 {
@@ -454,6 +656,23 @@ hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds, const Upd
         int per_query = kBatchBlocks / g.batch.queries;
         if (const char *f = getenv("LMCMA_HIP_BATCH_BLOCKS")) per_query = atoi(f) / g.batch.queries;
         blocks = std::min(blocks, std::max(per_query, 1));
+    }
+    // Many queries in one launch: the products on the matrix cores (k_generate_mfma), when nothing
+    // else has to ride in this launch.  From 16 queries on, as the one-workgroup ranking.
+    static const int mfma_from = getenv("LMCMA_HIP_MFMA_FROM") ? atoi(getenv("LMCMA_HIP_MFMA_FROM")) : 16;
+    if (J == 1 && g.batch.queries >= mfma_from && !cov && g.m <= 32 && g.cost.W + 4 <= 1024 &&
+        !(pre && pre->m <= 32 && !update_pre_rides_with_ranking(pre->m))) {
+        const size_t mlds = generate_mfma_lds_bytes(D, g.cost.W, g.m);
+        if (mlds <= budget) {
+            const int mtiles = (g.n_local + kMfmaTile - 1) / kMfmaTile;
+            int per_query = kBatchBlocks / g.batch.queries;
+            if (const char *f = getenv("LMCMA_HIP_BATCH_BLOCKS")) per_query = atoi(f) / g.batch.queries;
+            const int mblocks = std::min(mtiles, std::max(per_query, 1));
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_generate_mfma<D>), mlds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_generate_mfma<D>), dim3(mblocks, g.batch.queries), dim3(256), mlds, s, g);
+            return hipGetLastError();
+        }
     }
     if (cov) {
         if (vb_lds) return launch_t<J, D, false, true, true, false>(s, g, lds, blocks, nullptr);

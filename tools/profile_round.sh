@@ -19,4 +19,6 @@ for c in 3 4 5; do
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_c$c -o ${tag} -- $py tools/concurrent_queries.py batch $c 300 1 > $out/${tag}_c$c.log 2>&1 || exit 1
 done &&
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_q16 -o ${tag} -- $py tools/concurrent_queries.py batch 2 300 16 > $out/${tag}_q16.log 2>&1 &&
-$py profiles/summarize.py $out/${tag}_trace $out/${tag}_c3 $out/${tag}_c4 $out/${tag}_c5 $out/${tag}_q16
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_q64 -o ${tag} -- $py tools/concurrent_queries.py batch 2 300 64 > $out/${tag}_q64.log 2>&1 &&
+timeout -k 10 300 $py tools/concurrent_queries.py batch 2 400 1 2 4 8 16 32 64 > $out/${tag}_batched_queries.txt 2> /dev/null &&
+$py profiles/summarize.py $out/${tag}_trace $out/${tag}_c3 $out/${tag}_c4 $out/${tag}_c5 $out/${tag}_q16 $out/${tag}_q64
