@@ -219,7 +219,10 @@ int lmcma_hip_run(lmcma_hip_ctx *ctx, int n_generations);
  * initial paths: the reference's caller would run its ask/tell loop Q times, L/example_lmcma.cpp:
  * 47-60) and advances all of them with every launch: lmcma_hip_run(ctx, n) = n generations of
  * each.  Query q samples from the Philox key seed + q, so it is the run a one-query context
- * with that seed makes, bit for bit.  Needs lambda_local == lambda_total <= 16384, z_source
+ * with that seed makes: bit for bit with fewer than 12 queries; from 12 queries on every
+ * population is ranked by one workgroup and its elite rows are added in rank order, from 16 on
+ * the products of the sampling run on the matrix cores (same normals, same ranking, sums in
+ * another order: equal to rounding).  Needs lambda_local == lambda_total <= 16384, z_source
  * PHILOX, cost_source TRAJECTORY, m <= 64; the stepwise calls (set_state ... recombine) are not
  * available.  lmcma_hip_opt_init starts every query from the same mean and step size;
  * lmcma_hip_opt_set_query gives one query its own (and puts that query back to generation 0).

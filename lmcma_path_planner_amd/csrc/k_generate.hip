@@ -658,7 +658,8 @@ hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds, const Upd
         blocks = std::min(blocks, std::max(per_query, 1));
     }
     // Many queries in one launch: the products on the matrix cores (k_generate_mfma), when nothing
-    // else has to ride in this launch.  From 16 queries on, as the one-workgroup ranking.
+    // else has to ride in this launch.  From 16 queries on (lambda = 4096: no gain with 12, a loss
+    // with 8 and fewer, where the launch still waits for memory rather than for instruction issue).
     static const int mfma_from = getenv("LMCMA_HIP_MFMA_FROM") ? atoi(getenv("LMCMA_HIP_MFMA_FROM")) : 16;
     if (J == 1 && g.batch.queries >= mfma_from && !cov && g.m <= 32 && g.cost.W + 4 <= 1024 &&
         !(pre && pre->m <= 32 && !update_pre_rides_with_ranking(pre->m))) {

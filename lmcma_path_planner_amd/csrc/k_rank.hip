@@ -969,9 +969,10 @@ hipError_t launch_select(hipStream_t s, const SelectArgs &a, SelectResult *res)
     RankArgs r{};
     r.batch = a.batch.queries >= 1 ? a.batch : Batch{1, 0};
     // Many populations in one launch: one workgroup each (k_rank_sorted) instead of lambda / 32.
-    // From 16 queries on the launch is shorter that way (one query: 8.6 us by counting on every CU
-    // against some 15 us for the single workgroup and the recombination launch it needs).
-    static const int sorted_from = getenv("LMCMA_HIP_SORTED_RANK_FROM") ? atoi(getenv("LMCMA_HIP_SORTED_RANK_FROM")) : 16;
+    // From 12 queries on the generation is shorter that way (lambda = 4096: 70.7 against 76.0 us with
+    // 12 queries, 61.0 against 60.0 with 8; one query: 8.6 us by counting on every CU against some
+    // 25 us for the single workgroup and the recombination launch it needs).
+    static const int sorted_from = getenv("LMCMA_HIP_SORTED_RANK_FROM") ? atoi(getenv("LMCMA_HIP_SORTED_RANK_FROM")) : 12;
     if (a.tile_len == 0 && r.batch.queries >= sorted_from && lambda >= 1024 && lambda <= kSortedMax && lambda % kSortedBuckets == 0) {
         r.cost = a.cost_all;
         r.lambda = lambda;

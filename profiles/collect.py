@@ -22,7 +22,8 @@ import shutil
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CLASS_OF = {"k_generate": "generate", "k_sample": "sample", "k_cost": "cost", "k_rank": "select",
+CLASS_OF = {"k_generate": "generate", "k_generate_pre": "generate", "k_generate_mfma": "generate", "k_sample": "sample",
+            "k_cost": "cost", "k_rank": "select", "k_rank_sorted": "select", "k_rank_merge": "select",
             "k_sort_tiles": "select", "k_merge_rank": "select", "k_psr_count": "select",
             "k_recombine_partial": "recombine", "k_recombine_final": "recombine", "k_reduce_rows": "recombine",
             "k_update": "update", "k_update_pre": "update", "k_update_post": "update"}

@@ -157,7 +157,7 @@ def test_queries_argument_checks():
 
 @pytest.mark.parametrize("lam,mode,gens", [(4096, "random", 20), (2048, "random", 6), (1024, "ties", 4), (4096, "ties", 3)])
 def test_many_queries_are_ranked_one_workgroup_each(oracle, lam, mode, gens):
-    """From 16 queries on, every population of a context is ranked by one workgroup (a sample sort)
+    """From 12 queries on, every population of a context is ranked by one workgroup (a sample sort)
     and its elite rows are added by the rank-ordered recombination launch.  Checked per generation
     for three of the queries: the permutation and the sorted costs are those of a stable sort of the
     query's costs ("ties": degenerate bounds make all costs equal, so the order is the candidate
