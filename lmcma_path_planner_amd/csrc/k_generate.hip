@@ -416,14 +416,16 @@ __global__ __launch_bounds__(TB) void k_generate_pre(const GenParams g, const Up
 //   from LDS, B = D^T as the first product left it in registers (K index t = 4 (l / 16) + step),
 //   and the result lands chunk for chunk in the lane that drew that chunk.
 // The scoring half is the one of generate_body, 32 lanes per candidate, eight candidates per pass.
-// Rows of up to 128 floats, up to 32 direction vectors.
+// Rows of up to 128 floats, up to 16 direction vectors (one 16-row tile of D^T; with more vectors
+// the first part of the update rides in the sampling launch, which this kernel does not carry).
 constexpr int kMfmaLD = 132;    // LDS stride of a direction vector: 16-byte aligned, rows four banks apart
 constexpr int kMfmaTile = 64;   // candidates per workgroup pass (four waves)
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 size_t generate_mfma_lds_bytes(int D, int W, int m)
 {
-    const int mp = (m + 15) & ~15;
+    const int mp = 16;
+    (void)m;
     return ((size_t)kMfmaTile * padded_row_floats(D, W) + 2 * (size_t)mp * kMfmaLD + 3 * 128) * sizeof(float);
 }
 
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(256) void k_generate_mfma(const GenParams g)
     const int k = q_sc->k;
     const float sigma = q_sc->sigma, mk = q_sc->mk;
     const uint32_t generation = q_sc->generation;
-    const int mp = (g.m + 15) & ~15;
+    constexpr int mp = 16;
     const int LP = padded_row_floats(D, p.W);
     float *srows = smem;                        // [64][LP]
     float *sV = srows + kMfmaTile * LP;         // [mp][132], zero beyond the row and from vector k on
@@ -461,11 +463,11 @@ __global__ __launch_bounds__(256) void k_generate_mfma(const GenParams g)
             mv = reinterpret_cast<const float4 *>(src)[chunk < nchunks ? chunk : nchunks - 1];
             if (chunk >= nchunks) mv = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        float4 tv[4], tb[4];
+        float4 tv[2], tb[2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 2; ++u) {
             const int i = tid + 256 * u, row = i >> 5, chunk = i & 31;
-            const bool real = i < mp * 32 && row < g.m && chunk < nchunks;
+            const bool real = row < g.m && chunk < nchunks;
             const int at = real ? row * nchunks + chunk : 0;
             tv[u] = reinterpret_cast<const float4 *>(q_V)[at];
             tb[u] = reinterpret_cast<const float4 *>(q_B)[at];
@@ -473,14 +475,12 @@ __global__ __launch_bounds__(256) void k_generate_mfma(const GenParams g)
         asm volatile("" ::: "memory");
         if (tid < 96) reinterpret_cast<float4 *>(s_mean)[tid] = mv;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = tid + 256 * u, row = i >> 5, chunk = i & 31;
-            if (i < mp * 32) {
-                const bool real = row < g.m && row < k && chunk < nchunks;
-                const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4 *>(sV + row * kMfmaLD + 4 * chunk) = real ? tv[u] : zero;
-                *reinterpret_cast<float4 *>(sB + row * kMfmaLD + 4 * chunk) = real ? tb[u] : zero;
-            }
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 256 * u, row = i >> 5, chunk = i & 31;  // 16 rows x 32 chunks = 512
+            const bool real = row < g.m && row < k && chunk < nchunks;
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(sV + row * kMfmaLD + 4 * chunk) = real ? tv[u] : zero;
+            *reinterpret_cast<float4 *>(sB + row * kMfmaLD + 4 * chunk) = real ? tb[u] : zero;
         }
         // the fixed end points around every dimension of every row of the tile
         for (int i = tid; i < kMfmaTile * D * 4; i += 256) {
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void k_generate_mfma(const GenParams g)
         __syncthreads();  // staging done (first pass) / the previous tile's rows have been scored
 
         // ---- D^T = V Z^T
-        v4f dT0 = {0.f, 0.f, 0.f, 0.f}, dT1 = {0.f, 0.f, 0.f, 0.f};
+        v4f dT0 = {0.f, 0.f, 0.f, 0.f};
         if (k > 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -517,16 +517,6 @@ __global__ __launch_bounds__(256) void k_generate_mfma(const GenParams g)
                 dT0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, z[j].y, dT0, 0, 0, 0);
                 dT0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, z[j].z, dT0, 0, 0, 0);
                 dT0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va.w, z[j].w, dT0, 0, 0, 0);
-            }
-            if (k > 16) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float4 va = *reinterpret_cast<const float4 *>(sV + (16 + c16) * kMfmaLD + 4 * (q + 4 * j));
-                    dT1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, z[j].x, dT1, 0, 0, 0);
-                    dT1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, z[j].y, dT1, 0, 0, 0);
-                    dT1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, z[j].z, dT1, 0, 0, 0);
-                    dT1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va.w, z[j].w, dT1, 0, 0, 0);
-                }
             }
         }
 
@@ -542,13 +532,6 @@ __global__ __launch_bounds__(256) void k_generate_mfma(const GenParams g)
                 x = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[kMfmaLD], dT0[1], x, 0, 0, 0);
                 x = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[2 * kMfmaLD], dT0[2], x, 0, 0, 0);
                 x = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[3 * kMfmaLD], dT0[3], x, 0, 0, 0);
-                if (k > 16) {
-                    const float *b1 = b0 + 16 * kMfmaLD;
-                    x = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[0], dT1[0], x, 0, 0, 0);
-                    x = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[kMfmaLD], dT1[1], x, 0, 0, 0);
-                    x = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[2 * kMfmaLD], dT1[2], x, 0, 0, 0);
-                    x = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[3 * kMfmaLD], dT1[3], x, 0, 0, 0);
-                }
             }
             const int chunk = 4 * nt + q;
             if (chunk < nchunks) {
@@ -661,8 +644,7 @@ hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds, const Upd
     // else has to ride in this launch.  From 16 queries on (lambda = 4096: no gain with 12, a loss
     // with 8 and fewer, where the launch still waits for memory rather than for instruction issue).
     static const int mfma_from = getenv("LMCMA_HIP_MFMA_FROM") ? atoi(getenv("LMCMA_HIP_MFMA_FROM")) : 16;
-    if (J == 1 && g.batch.queries >= mfma_from && !cov && g.m <= 32 && g.cost.W + 4 <= 1024 &&
-        !(pre && pre->m <= 32 && !update_pre_rides_with_ranking(pre->m))) {
+    if (J == 1 && g.batch.queries >= mfma_from && !cov && g.m <= 16) {
         const size_t mlds = generate_mfma_lds_bytes(D, g.cost.W, g.m);
         if (mlds <= budget) {
             const int mtiles = (g.n_local + kMfmaTile - 1) / kMfmaTile;

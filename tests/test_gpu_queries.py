@@ -155,7 +155,8 @@ def test_queries_argument_checks():
     ctx.close()
 
 
-@pytest.mark.parametrize("lam,mode,gens", [(4096, "random", 20), (2048, "random", 6), (1024, "ties", 4), (4096, "ties", 3)])
+@pytest.mark.parametrize("lam,mode,gens", [(4096, "random", 20), (2048, "random", 6), (1024, "ties", 4), (4096, "ties", 3),
+                                           (1024, "3d", 12)])
 def test_many_queries_are_ranked_one_workgroup_each(oracle, lam, mode, gens):
     """From 12 queries on, every population of a context is ranked by one workgroup (a sample sort)
     and its elite rows are added by the rank-ordered recombination launch.  Checked per generation
@@ -167,15 +168,21 @@ def test_many_queries_are_ranked_one_workgroup_each(oracle, lam, mode, gens):
     import torch
     from lmcma_path_planner_amd import dist as shard_mod
     from lmcma_path_planner_amd import grids, hip
-    prob = grids.benchmark_problem(2)
     Q, m, seed = 16, 16, 31
+    if mode == "3d":
+        # rows shorter than the 128 floats of the matrix-core tiles (30 of 32 chunks), three
+        # dimensions, a float clearance-cost grid, fewer vectors than a tile has rows
+        prob = grids.Problem("t3d", dims=3, size=40, waypoints=40, lam=lam, m=9, esdf=True)
+        m, mode = 9, "random"
+    else:
+        prob = grids.benchmark_problem(2)
     dev = torch.device("cuda", 0)
     lo, hi = (prob.x0, prob.x0) if mode == "ties" else (prob.lo, prob.hi)
 
     def make(queries, s):
         c = hip.HipContext(prob.N, lam, m, dims=prob.dims, waypoints=prob.W, start=prob.start, goal=prob.goal, seed=s,
                            queries=queries)
-        c.set_grid(prob.occ)
+        c.set_grid(prob.cells)
         c.set_bounds(lo, hi)
         c.opt_init(prob.x0, prob.sigma0)
         return c
@@ -184,7 +191,7 @@ def test_many_queries_are_ranked_one_workgroup_each(oracle, lam, mode, gens):
     watch = (0, 7, 15)
     os_ = {q: oracle.OracleLMCMA(prob.N, lam, m, initial=prob.x0, lo=lo, hi=hi, sigma=prob.sigma0, seed=seed + q,
                                  z_source=oracle.Z_GIVEN) for q in watch}
-    co = oracle.CostOracle(2, prob.W, prob.occ, prob.start, prob.goal)
+    co = oracle.CostOracle(prob.dims, prob.W, prob.cells, prob.start, prob.goal)
     M = np.sqrt(1.0 - 1.0 / (10.0 * np.log(prob.N + 1.0)))      # lmcma.cpp:268, 431-447
     some = np.r_[0:48, lam - 16:lam]
     for g in range(gens):
