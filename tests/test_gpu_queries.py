@@ -156,7 +156,8 @@ def test_queries_argument_checks():
 
 
 @pytest.mark.parametrize("lam,mode,gens", [(4096, "random", 20), (2048, "random", 6), (1024, "ties", 4), (4096, "ties", 3),
-                                           (1024, "3d", 12)])
+                                           (1024, "3d", 12),
+                                           (1000, "random", 5)])    # counting rank, a last tile of 40 candidates
 def test_many_queries_are_ranked_one_workgroup_each(oracle, lam, mode, gens):
     """From 12 queries on, every population of a context is ranked by one workgroup (a sample sort)
     and its elite rows are added by the rank-ordered recombination launch.  Checked per generation
