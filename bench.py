@@ -302,6 +302,12 @@ def main():
                 b = algorithmic_bytes_per_launch(name, prob, lam_local, lam_total)
                 per_kernel[name] = {"avg_us": avg_s * 1e6, "bracket_us": ms * 1e3 / n, "launches": n, "bytes": b,
                                     "GBps": b / avg_s / 1e9}
+        if "update" in per_kernel and "generate" in per_kernel and per_kernel["update"]["launches"] < per_kernel["generate"]["launches"]:
+            # between two generations of one call the update runs at the head of the next sampling launch
+            g_ = per_kernel["generate"]
+            g_["carries"] = "the second part of the previous generation's update (all but the last generation of a call)"
+            g_["bytes"] += algorithmic_bytes_per_launch("update", prob, lam_local, lam_total)
+            g_["GBps"] = g_["bytes"] / (g_["avg_us"] * 1e-6) / 1e9
         dominant = max(per_kernel, key=lambda k: per_kernel[k]["avg_us"] * per_kernel[k]["launches"])
         # One generation = the chain of launches the library replays from its graph; its algorithmic
         # bytes are bytes-per-candidate x the candidates this GPU owns, its duration the device time of

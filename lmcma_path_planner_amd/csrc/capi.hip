@@ -152,6 +152,9 @@ struct lmcma_hip_ctx {
     float *best = nullptr;                      // a shard: lowest cost of the population
     bool ranked_local_only = false;             // the last ranking covered the local candidates only
     bool pre_done = false;   // the first part of this generation's update ran with a ranking launch
+    // the word on which workgroup 0 of a sampling launch that carries the previous generation's
+    // update waits for the other workgroups (GenParams::fused_counter); zero between launches
+    unsigned *fused_counter = nullptr;
     int psr_parts_n = 0;   // per-workgroup success-rule counts the last ranking left at the head of `keys`
     int32_t *perm = nullptr;
     uint64_t *keys = nullptr;
@@ -355,8 +358,11 @@ int do_evaluate(lmcma_hip_ctx *c)
 
 UpdateArgs update_args(const lmcma_hip_ctx *c, const double *partials, int n_partials, bool rows_with_scalars);
 
-// sample + score in one launch (device Philox stream only)
-int do_generate(lmcma_hip_ctx *c)
+// sample + score in one launch (device Philox stream only).
+// post: the previous generation's update, not yet applied, is to run at the head of this launch
+// (every workgroup computes it, the first stores it); *post_done = false: it cannot, nothing
+// has been launched, and the caller applies the update first.
+int do_generate(lmcma_hip_ctx *c, const UpdateArgs *post = nullptr, bool *post_done = nullptr)
 {
     Timed tm(c, LMCMA_K_GENERATE);
     GenParams g{};
@@ -370,6 +376,16 @@ int do_generate(lmcma_hip_ctx *c)
     g.cost = cost_params(c, c->rows, c->nloc, local_costs(c), c->terms);
     if (c->have_cov) g.cov = c->cov;
     g.batch = batch_of(c);
+    g.fused_counter = c->fused_counter;
+    if (post != nullptr) {
+        *post_done = false;
+        if (!c->pre_done || !generate_fuses(g, c->grid_lds, post)) return LMCMA_HIP_OK;
+        HIP_TRY(launch_generate(c->stream, g, c->D, c->grid_lds, nullptr, nullptr, post, post_done));
+        if (!*post_done) return fail(LMCMA_HIP_ERR_RUNTIME, "the sampling launch did not take the update it was to carry");
+        c->pre_done = false;  // (consumed, as launch_update_post would have)
+        c->sampled = true;
+        return LMCMA_HIP_OK;
+    }
     // the first part of this generation's update rides along when it is too long for the ranking launch
     const UpdateArgs pre = update_args(c, nullptr, 0, false);
     bool pre_done = false;
@@ -545,25 +561,39 @@ int do_update(lmcma_hip_ctx *c, const double *partials, int n_partials, bool row
     return LMCMA_HIP_OK;
 }
 
-int one_generation(lmcma_hip_ctx *c)
+// n generations in a row.  Between two of them the update of the first runs at the head of the
+// sampling launch of the second where that form exists (do_generate with post); the last
+// generation's update is a launch of its own, so the state is complete when the call returns.
+int generations(lmcma_hip_ctx *c, int n)
 {
-    int rc;
-    if (c->fused) {
-        if ((rc = do_generate(c)) != LMCMA_HIP_OK) return rc;
-    } else {
-        if ((rc = do_sample(c, nullptr)) != LMCMA_HIP_OK) return rc;
-        if ((rc = do_evaluate(c)) != LMCMA_HIP_OK) return rc;
-    }
-    int rows = 0;
-    if ((rc = do_select(c, true, &rows, true)) != LMCMA_HIP_OK) return rc;
-    if (rows == 0) {
-        if ((rc = do_recombine(c)) != LMCMA_HIP_OK) return rc;
-        rows = recombine_num_blocks(c->mu);
-    }
+    int rc, rows = 0;
     const double *src = nullptr;
-    if ((rc = reduce_if_many(c, &rows, &src)) != LMCMA_HIP_OK) return rc;
-    return do_update(c, src, rows, false);
+    for (int i = 0; i < n; ++i) {
+        bool carried = false;
+        if (i > 0) {
+            const UpdateArgs post = update_args(c, src, rows, false);
+            if (c->fused && (rc = do_generate(c, &post, &carried)) != LMCMA_HIP_OK) return rc;
+            if (!carried && (rc = do_update(c, src, rows, false)) != LMCMA_HIP_OK) return rc;
+        }
+        if (!carried) {
+            if (c->fused) {
+                if ((rc = do_generate(c)) != LMCMA_HIP_OK) return rc;
+            } else {
+                if ((rc = do_sample(c, nullptr)) != LMCMA_HIP_OK) return rc;
+                if ((rc = do_evaluate(c)) != LMCMA_HIP_OK) return rc;
+            }
+        }
+        if ((rc = do_select(c, true, &rows, true)) != LMCMA_HIP_OK) return rc;
+        if (rows == 0) {
+            if ((rc = do_recombine(c)) != LMCMA_HIP_OK) return rc;
+            rows = recombine_num_blocks(c->mu);
+        }
+        if ((rc = reduce_if_many(c, &rows, &src)) != LMCMA_HIP_OK) return rc;
+    }
+    return n > 0 ? do_update(c, src, rows, false) : LMCMA_HIP_OK;
 }
+
+int one_generation(lmcma_hip_ctx *c) { return generations(c, 1); }
 
 int check_ctx(const lmcma_hip_ctx *c)
 {
@@ -673,6 +703,7 @@ int lmcma_hip_create(const lmcma_hip_config *cfg, lmcma_hip_ctx **out)
     ar.add(&c->opt, 1);
     ar.add(&c->sc, 1);
     ar.add(&c->psr_accum, 1);
+    ar.add(&c->fused_counter, 1);
     ar.add(&c->t, m);
     ar.add(&c->vec, m);
     ar.add(&c->iterator, m);
@@ -1207,6 +1238,7 @@ int lmcma_hip_opt_reset(lmcma_hip_ctx *c)
     CTX_TRY(c);
     if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
     c->pre_done = false;
+    HIP_TRY(hipMemsetAsync(c->fused_counter, 0, sizeof(unsigned), c->stream));  // (a launch that gave up leaves it anywhere)
     hipLaunchKernelGGL(k_opt_reset, dim3(1, c->Q), dim3(256), 0, c->stream, c->opt, c->sc, c->xmean0,
                        c->xmean, c->xmean_f, c->pc, c->N, c->ld, c->psr_accum, c->qstride);
     HIP_TRY(hipGetLastError());
@@ -1271,7 +1303,7 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
                           "the sorted-cost buffers alternate per generation");
             HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             int crc = LMCMA_HIP_OK;
-            for (int g = 0; g < kGensPerGraph[q] && crc == LMCMA_HIP_OK; ++g) crc = one_generation(c);
+            crc = generations(c, kGensPerGraph[q]);
             hipError_t e = hipStreamEndCapture(c->stream, &c->graph[q]);
             if (crc != LMCMA_HIP_OK) { drop_graph(c); return crc; }
             if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
@@ -1287,8 +1319,8 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
     }
     for (int q = 0; use_graph && q < 2; ++q)
         for (; left >= kGensPerGraph[q]; left -= kGensPerGraph[q]) HIP_TRY(hipGraphLaunch(c->graph_exec[q], c->stream));
-    for (; left > 0; --left) {
-        int rc = one_generation(c);
+    if (left > 0) {
+        int rc = generations(c, left);
         if (rc != LMCMA_HIP_OK) return rc;
     }
     return LMCMA_HIP_OK;
@@ -1599,6 +1631,8 @@ int lmcma_hip_opt_get(lmcma_hip_ctx *c, lmcma_hip_opt_summary *summary, double *
     HIP_TRY(hipMemcpyAsync(&o, sel(c, c->opt), sizeof(o), hipMemcpyDeviceToHost, c->stream));
     if (xmean) HIP_TRY(hipMemcpyAsync(xmean, sel(c, c->xmean), c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (o.done == 3)
+        return fail(LMCMA_HIP_ERR_RUNTIME, "an update gave up waiting for the other workgroups of its launch; the state is stale");
     if (summary) {
         summary->itr = o.itr;
         summary->iterator_sz = o.iterator_sz;

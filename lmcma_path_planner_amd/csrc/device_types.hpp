@@ -81,6 +81,7 @@ struct GenParams {
     CostParams cost;          // cost.rows is not used: the rows come from LDS
     CovFactor cov;            // cov.L null: identity
     Batch batch;              // query q draws from the Philox key (key0 + q, key1)
+    unsigned *fused_counter;  // the fused form (launch_generate's post): a zeroed word of the context
 };
 
 // Raises a kernel's dynamic LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) when `lds`
@@ -92,8 +93,12 @@ hipError_t ensure_dynamic_lds(const void *kernel, size_t lds);
 struct UpdateArgs;
 // pre: the argument block of this generation's update when its first part may ride along as one
 // more workgroup of the launch (*pre_done tells whether it did); null: never
+// post: the complete argument block of the PREVIOUS generation's update when its second part may
+// run at the head of this launch, in every workgroup (*post_done tells whether it did); null: never
 hipError_t launch_generate(hipStream_t s, const GenParams &g, int dims, bool lds_grid, const UpdateArgs *pre = nullptr,
-                           bool *pre_done = nullptr);
+                           bool *pre_done = nullptr, const UpdateArgs *post = nullptr, bool *post_done = nullptr);
+// whether launch_generate would carry `post`
+bool generate_fuses(const GenParams &g, bool lds_grid, const UpdateArgs *post);
 
 // cov: null for the identity
 hipError_t launch_sample(hipStream_t s, float *rows, const float *zbuf, const float *xmean,

@@ -62,12 +62,17 @@ __host__ __device__ constexpr int pre_emax_for(int J, int N)
 // TB: threads per workgroup, 256 or 512 (TB / 32 candidates per pass).  The LDS copies of 32
 // long direction vectors leave room for one or two workgroups per CU; the larger workgroup
 // then has twice the waves share one copy.
-template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV, bool PRE, int TB>
+// FUSED: every workgroup first runs the second part of the PREVIOUS generation's update
+// (update_post_body<8, true>, the argument block in `pre`), which leaves the mean, the direction
+// vectors and the sampling scalars in LDS instead of sending them through memory and another
+// launch; workgroup 0 also stores the state.  512 threads, rows of up to 128 floats, one query.
+template <int J, int D, bool GRID_LDS, bool VB_LDS, bool COV, bool PRE, int TB, bool FUSED = false>
 __device__ __forceinline__ void generate_body(const GenParams &g, const UpdateArgs &pre)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int kTile = TB / kLanes;
     static_assert(TB == 256 || ((TB == 512) && !COV && !GRID_LDS), "the wide workgroup: plain variants only");
+    static_assert(!FUSED || (TB == 512 && J == 1 && VB_LDS && !PRE && !COV && !GRID_LDS), "the fused form: one variant");
     if (PRE && blockIdx.x == 0) {
         if (threadIdx.x >= 256) return;  // the first part of the update is a 256-thread workgroup
         // This workgroup is a chain of dependent steps that shares its CU with sampling workgroups:
@@ -104,10 +109,16 @@ __device__ __forceinline__ void generate_body(const GenParams &g, const UpdateAr
     const CostParams &p = g.cost;
     const int ld = g.ld;
     const int nchunks = ld >> 2;
-    const int k = q_sc->k;
-    const float sigma = q_sc->sigma;
-    const float mk = q_sc->mk;
-    const uint32_t generation = q_sc->generation;
+    // (the fused form gets these from the update it runs first, and must not wait for memory here)
+    int k = 0;
+    float sigma = 0.f, mk = 0.f;
+    uint32_t generation = 0u;
+    if (!FUSED) {
+        k = q_sc->k;
+        sigma = q_sc->sigma;
+        mk = q_sc->mk;
+        generation = q_sc->generation;
+    }
 
 #ifdef LMCMA_DIAG
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -125,22 +136,66 @@ __device__ __forceinline__ void generate_body(const GenParams &g, const UpdateAr
     float *sB = sV + (VB_LDS ? mp * LDP : 0);  // [mp][LDP] when VB_LDS, likewise
     float *s_z = sB + (VB_LDS ? mp * LDP : 0);  // [16][16 ntiles + 4] when COV
     uint32_t *sbits = reinterpret_cast<uint32_t *>(s_z + (COV ? factor_lds_floats(g.cov.ntiles) : 0));
+    // FUSED: [LDP] mean, [4] scalars, then the update's own LDS (doubles)
+    float *s_fx = s_z;
+    double *s_upd = reinterpret_cast<double *>(s_fx + LDP + 4);
 
     const int lane = threadIdx.x & (kLanes - 1);
     const int slot = threadIdx.x / kLanes;
-    // The update kernel wrote the mean and V, B, so their first touch misses this XCD's
-    // L2: every such load of the kernel is requested here, before anything waits.
-    // mean and bounds of this lane's chunks (used after the sampling loop)
+    // the bounds of this lane's chunks (used after the sampling loop): requested first
     float4 xm[J], l4[J], h4[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int chunk = j * kLanes + lane;
         const int cc = chunk < nchunks ? chunk : nchunks - 1;
-        xm[j] = reinterpret_cast<const float4 *>(q_xmean)[cc];
         l4[j] = reinterpret_cast<const float4 *>(q_lo)[cc];
         h4[j] = reinterpret_cast<const float4 *>(q_hi)[cc];
     }
-    if (VB_LDS) {
+    // FUSED: the normals of this workgroup's first tile, drawn while the update's partial rows arrive
+    float4 z_first[J];
+    bool from_update = false;
+    if (FUSED) {
+        for (int i = threadIdx.x; i < 2 * mp * (LDP >> 2); i += TB)
+            reinterpret_cast<float4 *>(sV)[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // (sB follows sV)
+        FusedOut fo{sV, sB, s_fx, s_fx + LDP, LDP, blockIdx.x == 0, g.fused_counter, gridDim.x - 1};
+        const int c0 = (int)blockIdx.x * kTile + slot;
+        const uint32_t cand0 = g.first_candidate + (uint32_t)(c0 < g.n_local ? c0 : g.n_local - 1);
+        auto draw = [&](uint32_t gen) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int chunk = j * kLanes + lane;
+                z_first[j] = (chunk < nchunks) ? philox_normals((uint32_t)chunk, cand0, gen, q_key0, g.key1)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        from_update = update_post_body<8, true>(pre, s_upd, 256, TB, &fo, draw);
+        __syncthreads();
+#ifdef LMCMA_DIAG
+        if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1)
+            for (int q = 0; q < 6; ++q) g_generate_stamps[8 + q] = g_update_stamps[q];
+#endif
+        if (from_update) {
+            sigma = s_fx[LDP];
+            mk = s_fx[LDP + 1];
+            k = __float_as_int(s_fx[LDP + 2]);
+            generation = __float_as_uint(s_fx[LDP + 3]);
+        } else {  // the stop rule has fired: the state in memory stays, sample from it
+            k = q_sc->k;
+            sigma = q_sc->sigma;
+            mk = q_sc->mk;
+            generation = q_sc->generation;
+        }
+    }
+    // The update kernel wrote the mean and V, B, so their first touch misses this XCD's
+    // L2: every such load of the kernel is requested here, before anything waits.
+    // mean and bounds of this lane's chunks (used after the sampling loop)
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int chunk = j * kLanes + lane;
+        const int cc = chunk < nchunks ? chunk : nchunks - 1;
+        xm[j] = (FUSED && from_update) ? reinterpret_cast<const float4 *>(s_fx)[cc] : reinterpret_cast<const float4 *>(q_xmean)[cc];
+    }
+    if (VB_LDS && !(FUSED && from_update)) {
         // All rows, whatever k is: the loads then do not wait for the scalar load of k (rows
         // from k on are stored as zeros: the sampling loop below runs in whole passes).
         const int n4 = mp * (LDP >> 2);
@@ -228,6 +283,10 @@ __device__ __forceinline__ void generate_body(const GenParams &g, const UpdateAr
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int chunk = j * kLanes + lane;
+            if (FUSED && from_update && tile == block) {
+                z[j] = z_first[j];
+                continue;
+            }
             z[j] = (chunk < nchunks) ? philox_normals((uint32_t)chunk, g.first_candidate + (uint32_t)c,
                                                       generation, q_key0, g.key1)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -399,6 +458,12 @@ template <int J, int D, bool VB_LDS, int TB>
 __global__ __launch_bounds__(TB) void k_generate_pre(const GenParams g, const UpdateArgs pre)
 {
     generate_body<J, D, false, VB_LDS, false, true, TB>(g, pre);
+}
+
+template <int D>
+__global__ __launch_bounds__(512) void k_generate_fused(const GenParams g, const UpdateArgs post)
+{
+    generate_body<1, D, false, true, false, false, 512, true>(g, post);
 }
 
 // ---- many queries per launch: the two products on the matrix cores ---------------------------
@@ -692,6 +757,30 @@ hipError_t launch_d(hipStream_t s, const GenParams &g, bool grid_lds, const Upda
     }
 }
 
+// The fused form: see generate_body.  One query, rows of up to 128 floats, up to 16 direction
+// vectors (the sizes whose first update part rides with the ranking), the grid read through L2.
+template <int D>
+hipError_t launch_fused(hipStream_t s, const GenParams &g, const UpdateArgs &post)
+{
+    constexpr int TB = 512, tile = TB / kLanes;
+    const size_t lds = ((size_t)tile * padded_row_floats(D, g.cost.W) + 2 * 16 * 128 + 128 + 4) * sizeof(float) +
+                       update_post_lds_doubles(post.N, post.m, TB) * sizeof(double);
+    const int ntiles = (g.n_local + tile - 1) / tile;
+    const int blocks = std::min(ntiles, 256);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_generate_fused<D>), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_generate_fused<D>), dim3(blocks, 1), dim3(TB), lds, s, g, post);
+    return hipGetLastError();
+}
+
+bool generate_can_fuse(const GenParams &g, bool grid_lds, const UpdateArgs *post)
+{
+    static const bool off = getenv("LMCMA_HIP_NO_FUSED_UPDATE") != nullptr;
+    return !off && post != nullptr && g.fused_counter != nullptr && g.batch.queries == 1 && g.ld <= 128 && g.cov.L == nullptr &&
+           !grid_lds && g.m <= 16 && post->N <= 128 && post->m == g.m && update_is_split(post->N, post->m) &&
+           update_pre_rides_with_ranking(post->m) && post->n_partials >= 1 && g.n_local >= 16;
+}
+
 }  // namespace
 
 #ifdef LMCMA_DIAG
@@ -701,10 +790,13 @@ extern "C" hipError_t lmcma_diag_generate_stamps(unsigned long long *out16)
 }
 #endif
 
+bool generate_fuses(const GenParams &g, bool grid_lds, const UpdateArgs *post) { return generate_can_fuse(g, grid_lds, post); }
+
 hipError_t launch_generate(hipStream_t s, const GenParams &g, int dims, bool grid_lds, const UpdateArgs *pre,
-                           bool *pre_done)
+                           bool *pre_done, const UpdateArgs *post, bool *post_done)
 {
     if (pre_done) *pre_done = false;
+    if (post_done) *post_done = false;
     if (g.n_local <= 0) return hipSuccess;
     if (g.batch.queries < 1) return hipErrorInvalidValue;
     if (g.ld <= 0 || (g.ld & 3) || g.ld > 512 || g.cost.W < 1 || dims * g.cost.W > g.ld)
@@ -713,6 +805,15 @@ hipError_t launch_generate(hipStream_t s, const GenParams &g, int dims, bool gri
     if (g.cov.L && (g.cov.ntiles < 1 || 16 * g.cov.ntiles < g.ld || g.cov.ntiles > 32 || g.cov.ld < 16 * g.cov.ntiles ||
                     (g.cov.ld & 3)))
         return hipErrorInvalidValue;
+    if (generate_can_fuse(g, grid_lds, post)) {
+        if (post_done) *post_done = true;
+        switch (dims) {
+            case 1: return launch_fused<1>(s, g, *post);
+            case 2: return launch_fused<2>(s, g, *post);
+            case 3: return launch_fused<3>(s, g, *post);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (dims) {
         case 1: return launch_d<1>(s, g, grid_lds, pre, pre_done);
         case 2: return launch_d<2>(s, g, grid_lds, pre, pre_done);

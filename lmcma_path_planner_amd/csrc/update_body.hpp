@@ -950,11 +950,37 @@ __host__ __device__ inline size_t update_post_lds_doubles(int N, int m, int TR)
     return (size_t)m * np + np + row_sum_lds_doubles(N, TR) + LMCMA_HIP_MAX_VECTORS;
 }
 
+// What the second part leaves in LDS when it runs at the head of the next generation's sampling
+// launch, in EVERY workgroup of it (update_post_body<EMAX, true>): the float images the sampling
+// reads, by position, and the sampling scalars.  Only the workgroup with write_state stores
+// the state to memory.
+struct FusedOut {
+    float *sV, *sB;   // [rows][ldp], zeroed by the caller before the call; rows from k on stay zero
+    float *s_xmean;   // [ldp]
+    float *s_scal;    // [4]: sigma, M^k, k (bits of an int), generation (bits of a uint32)
+    int ldp;
+    bool write_state;
+    // The storing workgroup overwrites state the others read at their start: every other
+    // workgroup reports here once all its loads have arrived, and the storing one waits for
+    // `others` reports before its first store (then puts the word back to zero).
+    unsigned *counter;
+    unsigned others;
+};
+
+struct NoHook {
+    __device__ __forceinline__ void operator()(uint32_t) const {}
+};
+
 // Second part; thread roles as in update_body (T workers, TR row readers, the first wave
-// past the workers evaluates the step-size rule).
-template <int EMAX>
-__device__ __forceinline__ void update_post_body(const UpdateArgs &a, double *s_dyn, int T, int TR)
+// past the workers evaluates the step-size rule).  Returns false when the stop rule had fired
+// and nothing was done.  FUSED: see FusedOut; hook(generation) is called once the scalars of the
+// state have arrived and the partial rows are still on their way (work that needs no more than
+// the number of the generation about to be sampled).
+template <int EMAX, bool FUSED = false, typename Hook = NoHook>
+__device__ __forceinline__ bool update_post_body(const UpdateArgs &a, double *s_dyn, int T, int TR,
+                                                 const FusedOut *fo = nullptr, Hook hook = NoHook())
 {
+    const bool ws = !FUSED || fo->write_state;  // this workgroup stores the state
     constexpr bool KEEP_PC = EMAX <= 16;  // the paths stay in registers (re-read at the end otherwise)
     const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wl = tid & 63;
     const int N = a.N, m = a.m, lambda = a.lambda;
@@ -1027,8 +1053,9 @@ __device__ __forceinline__ void update_post_body(const UpdateArgs &a, double *s_
     RowSumBatch first_rows;
     row_sums_begin(a.partials, a.n_partials, N, a.partial_stride, TR, first_rows);
     asm volatile("" ::: "memory");
-    if (done) return;  // the stop rule has fired: the state stays as it is
+    if (done) return false;  // the stop rule has fired: the state stays as it is
     LMCMA_STAMP(1);
+    hook((uint32_t)(itr + 1));
 
     const SlotPlan sp = slot_plan(t_reg, vec_reg, itr, m, tid);
     t_reg = sp.t_reg;
@@ -1084,6 +1111,8 @@ __device__ __forceinline__ void update_post_body(const UpdateArgs &a, double *s_
     row_sums_to_lds_t<true>(a.partials, a.n_partials, N, a.partial_stride, TR, s_red, first_rows);
     __syncthreads();
     LMCMA_STAMP(2);
+    // (every load of this workgroup has arrived: the barrier above waited for them)
+    if (FUSED && !ws && tid == 0) __hip_atomic_fetch_add(fo->counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // L/:316-329: new mean, evolution path
     double xnew[2] = {0.0, 0.0}, pcn[2] = {0.0, 0.0};
 #pragma unroll
@@ -1147,24 +1176,49 @@ __device__ __forceinline__ void update_post_body(const UpdateArgs &a, double *s_
     }
     LMCMA_STAMP(4);
 
+    bool stores_ok = true;
+    if (FUSED && ws && fo->others > 0) {
+        // the other workgroups of the launch must have read the old state before it is overwritten
+        __shared__ int s_go;
+        if (tid == 0) {
+            int spins = 0, ok = 1;
+            while (__hip_atomic_load(fo->counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fo->others) {
+                if (++spins > (1 << 23)) {  // about a second: the exit every wave reaches whatever the others do
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s_go = ok;
+        }
+        __syncthreads();
+        stores_ok = s_go != 0;
+        if (tid == 0) {
+            *fo->counter = 0u;
+            if (!stores_ok) o.done = 3;  // reported by the host as an error; the state is left as it was
+        }
+    }
+    const bool wst = ws && stores_ok;
+
     // state back to memory, and the float images the sampling kernel reads, by position q:
     // V_f[q] = v_q, B_f[q] = M^(k-1-q) nj_q pc_q
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int n = tid + q * T;
-        if (worker && n < N) {
+        if (wst && worker && n < N) {
             a.xmean[n] = xnew[q];
             a.pc[n] = pcn[q];
         }
-        if (worker && n < a.ld) a.xmean_f[n] = (n < N) ? (float)xnew[q] : 0.f;
+        if (wst && worker && n < a.ld) a.xmean_f[n] = (n < N) ? (float)xnew[q] : 0.f;
+        if (FUSED && worker && n < fo->ldp) fo->s_xmean[n] = (n < N) ? (float)xnew[q] : 0.f;
     }
-    if (tid < m) {
+    if (wst && tid < m) {
         a.t[tid] = t_reg;
         a.vec[tid] = vec_reg;
         if (tid < isz) a.iterator[tid] = t_reg;
     }
     if (own) {
-        if (newest && lane == 0) {
+        if (wst && newest && lane == 0) {
             a.nj[slot] = nj_new;
             a.lj[slot] = lj_new;
         }
@@ -1175,32 +1229,46 @@ __device__ __forceinline__ void update_post_body(const UpdateArgs &a, double *s_
             const int n = e * 16 + lane;
             double pv = pcq[e];
             if (!KEEP_PC) pv = n < N ? (newest ? s_pc[n] : a.pc_arr[(size_t)slot * N + n]) : 0.0;
-            if (n < N && newest) {
+            if (wst && n < N && newest) {
                 a.pc_arr[(size_t)slot * N + n] = pv;
                 a.v_arr[(size_t)slot * N + n] = av[e];
             }
-            if (n < a.ld) {
-                a.V_f[(size_t)pos * a.ld + n] = (n < N) ? (float)av[e] : 0.f;
-                a.B_f[(size_t)pos * a.ld + n] = (n < N) ? (float)(coef * pv) : 0.f;
+            const float vf = (n < N) ? (float)av[e] : 0.f, bf = (n < N) ? (float)(coef * pv) : 0.f;
+            if (wst && n < a.ld) {
+                a.V_f[(size_t)pos * a.ld + n] = vf;
+                a.B_f[(size_t)pos * a.ld + n] = bf;
+            }
+            if (FUSED && n < fo->ldp) {
+                fo->sV[pos * fo->ldp + n] = vf;
+                fo->sB[pos * fo->ldp + n] = bf;
             }
         }
     }
     if (tid == stid) {
-        o.s = new_s;
-        o.sigma = new_sigma;
-        o.best_f = new_best;
-        o.counteval = new_counteval;
-        o.itr = itr + 1;
-        o.iterator_sz = isz;
-        o.imin_last = imin;
-        o.done = new_sigma < 1e-20 ? 1 : 0;  // L/:426-429
-        a.sc->sigma = (float)new_sigma;
-        a.sc->mk = (float)mk;
-        a.sc->k = isz;
-        a.sc->generation = (uint32_t)(itr + 1);
-        *a.psr_accum = 0ull;
+        if (wst) {
+            o.s = new_s;
+            o.sigma = new_sigma;
+            o.best_f = new_best;
+            o.counteval = new_counteval;
+            o.itr = itr + 1;
+            o.iterator_sz = isz;
+            o.imin_last = imin;
+            o.done = new_sigma < 1e-20 ? 1 : 0;  // L/:426-429
+            a.sc->sigma = (float)new_sigma;
+            a.sc->mk = (float)mk;
+            a.sc->k = isz;
+            a.sc->generation = (uint32_t)(itr + 1);
+            *a.psr_accum = 0ull;
+        }
+        if (FUSED) {
+            fo->s_scal[0] = (float)new_sigma;
+            fo->s_scal[1] = (float)mk;
+            fo->s_scal[2] = __int_as_float(isz);
+            fo->s_scal[3] = __uint_as_float((uint32_t)(itr + 1));
+        }
     }
     LMCMA_STAMP(5);
+    return true;
 }
 
 }  // namespace lmcma
