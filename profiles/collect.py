@@ -22,7 +22,8 @@ import shutil
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CLASS_OF = {"k_generate": "generate", "k_generate_pre": "generate", "k_generate_mfma": "generate", "k_sample": "sample",
+CLASS_OF = {"k_generate": "generate", "k_generate_pre": "generate", "k_generate_mfma": "generate",
+            "k_generate_fused": "generate+update", "k_sample": "sample",
             "k_cost": "cost", "k_rank": "select", "k_rank_sorted": "select", "k_rank_merge": "select",
             "k_sort_tiles": "select", "k_merge_rank": "select", "k_psr_count": "select",
             "k_recombine_partial": "recombine", "k_recombine_final": "recombine", "k_reduce_rows": "recombine",
@@ -50,6 +51,7 @@ def main():
     if len(sys.argv) >= 5:
         fe, wr = pmc(sys.argv[3]), pmc(sys.argv[4])
         per_class = collections.defaultdict(float)
+        total, generations = 0.0, 0
         with open(os.path.join(HERE, tag + "_hbm_traffic.csv"), "w") as out:
             out.write("kernel,launches,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,corrected_bytes_per_launch\n")
             for k in sorted(fe):
@@ -58,7 +60,12 @@ def main():
                 out.write("%s,%d,%.3f,%.3f,%.0f\n" % (k, fe[k][0], f_kb, w_kb, (2 * f_kb + w_kb) * 1024.0))
                 if k in CLASS_OF:
                     per_class[CLASS_OF[k]] += (2 * f_kb + w_kb) * 1024.0
-        per_class["generation"] = sum(per_class.values())   # all launches of one generation together
+                    total += (2 * f_kb + w_kb) * 1024.0 * fe[k][0]
+                    if CLASS_OF[k] == "select":
+                        generations = max(generations, fe[k][0])   # every generation has one ranking launch
+        # all launches of the run together, per generation (inside a call the update rides in the
+        # next sampling launch, so the kernels are not launched equally often)
+        per_class["generation"] = total / max(generations, 1)
         json.dump({k: round(v) for k, v in per_class.items()}, open(os.path.join(HERE, "traffic_cfg2.json"), "w"),
                   indent=1, sort_keys=True)
 
