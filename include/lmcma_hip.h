@@ -209,11 +209,14 @@ int lmcma_hip_opt_reset(lmcma_hip_ctx *ctx);
  * L/lmcma.cpp:426-429); here the update kernels evaluate that rule: once it has
  * fired the state is left as it is, so generations queued beyond it change
  * nothing and lmcma_hip_opt_summary.itr is the generation that reached it.
- * The first call on a context also records the HIP graphs later calls replay. */
+ * The first call on a context also records the HIP graphs later calls replay.
+ * Inside a call the update of one generation may run at the head of the next generation's
+ * sampling launch; the state in memory is complete when the call's work has finished, as with
+ * the stepwise calls, and the results are the same bits.                                  */
 int lmcma_hip_run(lmcma_hip_ctx *ctx, int n_generations);
 
 /* ---- several queries in one context ------------------------------------------------
- * One optimiser's generation is a chain of three dependent launches that leaves most of the
+ * One optimiser's generation is a chain of two or three dependent launches that leaves most of the
  * GPU idle.  A context created with queries = Q > 1 holds Q independent optimisers on the same
  * map, start, goal, bounds and sizes (restarts of one planning problem from different seeds or
  * initial paths: the reference's caller would run its ask/tell loop Q times, L/example_lmcma.cpp:
