@@ -151,6 +151,31 @@ __device__ __forceinline__ uint32_t add_lane_xor32(uint32_t v)
     return r[0] + r[1];
 }
 
+// the same exchanges for a double: its two words travel separately
+__device__ __forceinline__ double add_lane_xor16(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const auto lo = __builtin_amdgcn_permlane16_swap((uint32_t)b, (uint32_t)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((uint32_t)(b >> 32), (uint32_t)(b >> 32), false, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]) +
+           __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+}
+
+__device__ __forceinline__ double add_lane_xor32(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const auto lo = __builtin_amdgcn_permlane32_swap((uint32_t)b, (uint32_t)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((uint32_t)(b >> 32), (uint32_t)(b >> 32), false, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]) +
+           __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+}
+
+// sum over the 64 lanes of a wave, identical bits in every lane
+__device__ __forceinline__ double wave_sum(double v)
+{
+    return add_lane_xor32(add_lane_xor16(row16_sum(v)));
+}
+
 template <int G>
 __device__ __forceinline__ float group_sum(float v)
 {

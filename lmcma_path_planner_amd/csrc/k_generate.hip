@@ -172,7 +172,7 @@ __device__ __forceinline__ void generate_body(const GenParams &g, const UpdateAr
         __syncthreads();
 #ifdef LMCMA_DIAG
         if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1)
-            for (int q = 0; q < 6; ++q) g_generate_stamps[8 + q] = g_update_stamps[q];
+            for (int q = 0; q < 8; ++q) g_generate_stamps[8 + q] = g_update_stamps[q];
 #endif
         if (from_update) {
             sigma = s_fx[LDP];

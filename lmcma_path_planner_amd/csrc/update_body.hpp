@@ -976,6 +976,16 @@ struct NoHook {
 // and nothing was done.  FUSED: see FusedOut; hook(generation) is called once the scalars of the
 // state have arrived and the partial rows are still on their way (work that needs no more than
 // the number of the generation about to be sampled).
+// phase stamps of the second part (diagnostic build): in the fused form by the launch's last workgroup only
+#ifdef LMCMA_DIAG
+#define POST_STAMP(i)                                                                               \
+    do {                                                                                            \
+        if (threadIdx.x == 0 && (!FUSED || blockIdx.x == gridDim.x - 1))                            \
+            g_update_stamps[i] = __builtin_amdgcn_s_memrealtime();                                  \
+    } while (0)
+#else
+#define POST_STAMP(i)
+#endif
 template <int EMAX, bool FUSED = false, typename Hook = NoHook>
 __device__ __forceinline__ bool update_post_body(const UpdateArgs &a, double *s_dyn, int T, int TR,
                                                  const FusedOut *fo = nullptr, Hook hook = NoHook())
@@ -1000,7 +1010,7 @@ __device__ __forceinline__ bool update_post_body(const UpdateArgs &a, double *s_
     double *s_red = s_pc + NP;                   // [rg][N]
     double *s_ljp = s_red + row_sum_lds_doubles(N, TR);  // [64] lj by position
 
-    LMCMA_STAMP(0);
+    POST_STAMP(0);
     int t_reg = 0, vec_reg = 0;
     if (wl < m) {
         t_reg = a.t[wl];
@@ -1054,7 +1064,7 @@ __device__ __forceinline__ bool update_post_body(const UpdateArgs &a, double *s_
     row_sums_begin(a.partials, a.n_partials, N, a.partial_stride, TR, first_rows);
     asm volatile("" ::: "memory");
     if (done) return false;  // the stop rule has fired: the state stays as it is
-    LMCMA_STAMP(1);
+    POST_STAMP(1);
     hook((uint32_t)(itr + 1));
 
     const SlotPlan sp = slot_plan(t_reg, vec_reg, itr, m, tid);
@@ -1110,7 +1120,7 @@ __device__ __forceinline__ bool update_post_body(const UpdateArgs &a, double *s_
     }
     row_sums_to_lds_t<true>(a.partials, a.n_partials, N, a.partial_stride, TR, s_red, first_rows);
     __syncthreads();
-    LMCMA_STAMP(2);
+    POST_STAMP(2);
     // (every load of this workgroup has arrived: the barrier above waited for them)
     if (FUSED && !ws && tid == 0) __hip_atomic_fetch_add(fo->counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // L/:316-329: new mean, evolution path
@@ -1126,55 +1136,128 @@ __device__ __forceinline__ bool update_post_body(const UpdateArgs &a, double *s_
     }
     for (int n = N + tid; n < NP; n += (int)blockDim.x) s_pc[n] = 0.0;
     __syncthreads();
-    LMCMA_STAMP(3);
+    POST_STAMP(3);
 
-    // L/:375-390 with invAz (:449-463) for the newest vector: v = T_{k-2} ... T_0 pc
-    double nj_new = nj_old, lj_new = lj_old;
-    if (newest) {
+    // L/:375-390 with invAz (:449-463) for the newest vector: v = T_{k-2} ... T_0 pc.  Its steps
+    // depend on each other, and a step is bound by the issue of its fp64 instructions, so the
+    // whole wave that holds the newest slot's group walks the chain, 64 lanes wide (coordinate
+    // n = 64 j + lane; both operands come from LDS, so the lanes' other roles do not matter):
+    // EMAX / 4 multiply-adds per lane and step where one 16-lane group needs EMAX.  The wave
+    // also stores everything of the newest slot.
+    constexpr int EW = (NP + 63) / 64;
+    const bool chain_wave = worker && (tid >> 6) == (newidx >> 2);
+    double avw[EW], pcw[EW];
+    double nj_w = 0.0, lj_w = 0.0;
 #pragma unroll
-        for (int e = 0; e < EMAX; ++e) {
-            av[e] = s_pc[e * 16 + lane];
-            pcq[e] = av[e];
+    for (int j = 0; j < EW; ++j) avw[j] = pcw[j] = 0.0;
+    if (chain_wave) {
+#ifdef LMCMA_DIAG
+        if (wl == 0 && (!FUSED || blockIdx.x == gridDim.x - 1)) g_update_stamps[6] = __builtin_amdgcn_s_memrealtime();
+#endif
+        double vv[EW];
+#pragma unroll
+        for (int j = 0; j < EW; ++j) {
+            const int n = j * 64 + wl;
+            const bool in = EW * 64 == NP || n < NP;
+            avw[j] = pcw[j] = in ? s_pc[in ? n : 0] : 0.0;
+            vv[j] = in ? s_v[in ? n : 0] : 0.0;
         }
-        // the steps depend on each other through av only: the next vector and its lj are read
-        // from LDS while this step's sums are under way
-        double vv[EMAX];
-#pragma unroll
-        for (int e = 0; e < EMAX; ++e) vv[e] = s_v[e * 16 + lane];
         double lji = s_ljp[0];
         for (int i = 0; i < isz - 1; ++i) {
+            // the next vector and its lj are requested before this step's sums are under way
             const int nx = i + 1 < isz - 1 ? i + 1 : i;
             const double *vn = s_v + (size_t)nx * NP;
-            double vnext[EMAX];
+            double vnext[EW];
 #pragma unroll
-            for (int e = 0; e < EMAX; ++e) vnext[e] = vn[e * 16 + lane];
+            for (int j = 0; j < EW; ++j) {
+                const int n = j * 64 + wl;
+                const bool in = EW * 64 == NP || n < NP;
+                vnext[j] = in ? vn[in ? n : 0] : 0.0;
+            }
             const double ljn = s_ljp[nx];
+            asm volatile("" ::: "memory");  // (keeps the requests above this step's arithmetic)
             double p0 = 0.0, p1 = 0.0;
 #pragma unroll
-            for (int e = 0; e < EMAX; e += 2) {
-                p0 += vv[e] * av[e];
-                p1 += vv[e + 1] * av[e + 1];
+            for (int j = 0; j < EW; j += 2) {
+                p0 += vv[j] * avw[j];
+                if (j + 1 < EW) p1 += vv[j + 1] * avw[j + 1];
             }
-            const double d = lji * row16_sum(p0 + p1);
+            const double d = lji * wave_sum(p0 + p1);
 #pragma unroll
-            for (int e = 0; e < EMAX; ++e) {
-                av[e] = K * av[e] - d * vv[e];
-                vv[e] = vnext[e];
+            for (int j = 0; j < EW; ++j) {
+                avw[j] = K * avw[j] - d * vv[j];
+                vv[j] = vnext[j];
             }
             lji = ljn;
         }
         double aa = 0.0;
 #pragma unroll
-        for (int e = 0; e < EMAX; ++e) aa += av[e] * av[e];
-        aa = row16_sum(aa);
-        nj_new = (sq / aa) * (sqrt(1 + ratio * aa) - 1);
-        lj_new = lj_of(aa, sq, ratio);
+        for (int j = 0; j < EW; ++j) aa += avw[j] * avw[j];
+        aa = wave_sum(aa);
+        nj_w = (sq / aa) * (sqrt(1 + ratio * aa) - 1);
+        lj_w = lj_of(aa, sq, ratio);
+#ifdef LMCMA_DIAG
+        if (wl == 0 && (!FUSED || blockIdx.x == gridDim.x - 1)) g_update_stamps[7] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
-    if (!KEEP_PC) {
+    POST_STAMP(4);
+
+    // What the sampling reads, by position q: V_f[q] = v_q, B_f[q] = M^(k-1-q) nj_q pc_q.  FUSED:
+    // into this workgroup's LDS (no address outside LDS is formed on this path).
+    const bool older = own && !newest;
+    float vf[EMAX], bf[EMAX];
+    if (older) {
+        double coef = nj_old;
+        for (int e = 0; e < isz - 1 - pos; ++e) coef *= Mfac;
 #pragma unroll
-        for (int e = 0; e < EMAX; ++e) pcq[e] = 0.0;
+        for (int e = 0; e < EMAX; ++e) {
+            const int n = e * 16 + lane;
+            double pv = pcq[e];
+            if (!KEEP_PC) pv = n < N ? a.pc_arr[(size_t)slot * N + n] : 0.0;
+            vf[e] = (n < N) ? (float)av[e] : 0.f;
+            bf[e] = (n < N) ? (float)(coef * pv) : 0.f;
+        }
     }
-    LMCMA_STAMP(4);
+    float vfw[EW], bfw[EW];
+#pragma unroll
+    for (int j = 0; j < EW; ++j) {
+        const int n = j * 64 + wl;
+        vfw[j] = (n < N) ? (float)avw[j] : 0.f;
+        bfw[j] = (n < N) ? (float)(nj_w * pcw[j]) : 0.f;
+    }
+    if (FUSED) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int n = tid + q * T;
+            if (worker && n < fo->ldp) fo->s_xmean[n] = (n < N) ? (float)xnew[q] : 0.f;
+        }
+        if (older) {
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) {
+                const int n = e * 16 + lane;
+                if (n < fo->ldp) {
+                    fo->sV[pos * fo->ldp + n] = vf[e];
+                    fo->sB[pos * fo->ldp + n] = bf[e];
+                }
+            }
+        }
+        if (chain_wave) {
+#pragma unroll
+            for (int j = 0; j < EW; ++j) {
+                const int n = j * 64 + wl;
+                if (n < NP && n < fo->ldp) {
+                    fo->sV[(isz - 1) * fo->ldp + n] = vfw[j];
+                    fo->sB[(isz - 1) * fo->ldp + n] = bfw[j];
+                }
+            }
+        }
+        if (tid == stid) {
+            fo->s_scal[0] = (float)new_sigma;
+            fo->s_scal[1] = (float)mk;
+            fo->s_scal[2] = __int_as_float(isz);
+            fo->s_scal[3] = __uint_as_float((uint32_t)(itr + 1));
+        }
+    }
 
     bool stores_ok = true;
     if (FUSED && ws && fo->others > 0) {
@@ -1198,54 +1281,52 @@ __device__ __forceinline__ bool update_post_body(const UpdateArgs &a, double *s_
             if (!stores_ok) o.done = 3;  // reported by the host as an error; the state is left as it was
         }
     }
-    const bool wst = ws && stores_ok;
 
-    // state back to memory, and the float images the sampling kernel reads, by position q:
-    // V_f[q] = v_q, B_f[q] = M^(k-1-q) nj_q pc_q
+    // the state back to memory, by the one workgroup that stores it
+    if (ws && stores_ok) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int n = tid + q * T;
-        if (wst && worker && n < N) {
-            a.xmean[n] = xnew[q];
-            a.pc[n] = pcn[q];
+        for (int q = 0; q < 2; ++q) {
+            const int n = tid + q * T;
+            if (worker && n < N) {
+                a.xmean[n] = xnew[q];
+                a.pc[n] = pcn[q];
+            }
+            if (worker && n < a.ld) a.xmean_f[n] = (n < N) ? (float)xnew[q] : 0.f;
         }
-        if (wst && worker && n < a.ld) a.xmean_f[n] = (n < N) ? (float)xnew[q] : 0.f;
-        if (FUSED && worker && n < fo->ldp) fo->s_xmean[n] = (n < N) ? (float)xnew[q] : 0.f;
-    }
-    if (wst && tid < m) {
-        a.t[tid] = t_reg;
-        a.vec[tid] = vec_reg;
-        if (tid < isz) a.iterator[tid] = t_reg;
-    }
-    if (own) {
-        if (wst && newest && lane == 0) {
-            a.nj[slot] = nj_new;
-            a.lj[slot] = lj_new;
+        if (tid < m) {
+            a.t[tid] = t_reg;
+            a.vec[tid] = vec_reg;
+            if (tid < isz) a.iterator[tid] = t_reg;
         }
-        double coef = nj_new;
-        for (int e = 0; e < isz - 1 - pos; ++e) coef *= Mfac;
+        if (older) {
 #pragma unroll
-        for (int e = 0; e < EMAX; ++e) {
-            const int n = e * 16 + lane;
-            double pv = pcq[e];
-            if (!KEEP_PC) pv = n < N ? (newest ? s_pc[n] : a.pc_arr[(size_t)slot * N + n]) : 0.0;
-            if (wst && n < N && newest) {
-                a.pc_arr[(size_t)slot * N + n] = pv;
-                a.v_arr[(size_t)slot * N + n] = av[e];
-            }
-            const float vf = (n < N) ? (float)av[e] : 0.f, bf = (n < N) ? (float)(coef * pv) : 0.f;
-            if (wst && n < a.ld) {
-                a.V_f[(size_t)pos * a.ld + n] = vf;
-                a.B_f[(size_t)pos * a.ld + n] = bf;
-            }
-            if (FUSED && n < fo->ldp) {
-                fo->sV[pos * fo->ldp + n] = vf;
-                fo->sB[pos * fo->ldp + n] = bf;
+            for (int e = 0; e < EMAX; ++e) {
+                const int n = e * 16 + lane;
+                if (n < a.ld) {
+                    a.V_f[(size_t)pos * a.ld + n] = vf[e];
+                    a.B_f[(size_t)pos * a.ld + n] = bf[e];
+                }
             }
         }
-    }
-    if (tid == stid) {
-        if (wst) {
+        if (chain_wave) {
+            if (wl == 0) {
+                a.nj[newidx] = nj_w;
+                a.lj[newidx] = lj_w;
+            }
+#pragma unroll
+            for (int j = 0; j < EW; ++j) {
+                const int n = j * 64 + wl;
+                if (n < N) {
+                    a.pc_arr[(size_t)newidx * N + n] = pcw[j];
+                    a.v_arr[(size_t)newidx * N + n] = avw[j];
+                }
+                if (n < NP && n < a.ld) {
+                    a.V_f[(size_t)(isz - 1) * a.ld + n] = vfw[j];
+                    a.B_f[(size_t)(isz - 1) * a.ld + n] = bfw[j];
+                }
+            }
+        }
+        if (tid == stid) {
             o.s = new_s;
             o.sigma = new_sigma;
             o.best_f = new_best;
@@ -1260,15 +1341,11 @@ __device__ __forceinline__ bool update_post_body(const UpdateArgs &a, double *s_
             a.sc->generation = (uint32_t)(itr + 1);
             *a.psr_accum = 0ull;
         }
-        if (FUSED) {
-            fo->s_scal[0] = (float)new_sigma;
-            fo->s_scal[1] = (float)mk;
-            fo->s_scal[2] = __int_as_float(isz);
-            fo->s_scal[3] = __uint_as_float((uint32_t)(itr + 1));
-        }
     }
-    LMCMA_STAMP(5);
+    POST_STAMP(5);
     return true;
 }
+
+#undef POST_STAMP
 
 }  // namespace lmcma

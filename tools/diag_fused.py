@@ -19,5 +19,5 @@ for g in (10, 20, 30, 40):
     t0 = int(sg[0])
     rel = lambda i: (int(sg[i]) - t0) * 10
     print("update in the launch: start %d, loads issued %d, rows summed %d, mean+path %d, newest vector %d, stores %d | "
-          "sampling: normals %d, barrier %d, directions %d, rows out %d, scored %d, end %d"
-          % (rel(8), rel(9), rel(10), rel(11), rel(12), rel(13), rel(1), rel(2), rel(3), rel(4), rel(5), rel(6)), flush=True)
+          "newest vector's group: from %d to %d | sampling: normals %d, barrier %d, directions %d, rows out %d, scored %d, end %d"
+          % (rel(8), rel(9), rel(10), rel(11), rel(12), rel(13), rel(14), rel(15), rel(1), rel(2), rel(3), rel(4), rel(5), rel(6)), flush=True)
