@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -79,8 +80,10 @@ __global__ void k_set_sample_scalars(SampleScalars *sc, float sigma, float mk, i
 // back to the state lmcma_hip_opt_init left: mean, step size, empty direction store
 __global__ void k_opt_reset(OptScalars *opt, SampleScalars *sc, const double *xmean0,
                             double *xmean, float *xmean_f, double *pc, int N, int ld,
-                            unsigned long long *psr_accum, size_t qstride)
+                            unsigned long long *psr_accum, size_t qstride, unsigned *fused_counter)
 {
+    // (the counter of the fused update: a launch that gave up leaves it anywhere; not per query)
+    if (fused_counter && blockIdx.y == 0 && threadIdx.x == 0) *fused_counter = 0u;
     const size_t off = (size_t)blockIdx.y * qstride;  // query blockIdx.y of a batch
     shift_ptr(opt, off); shift_ptr(sc, off); shift_ptr(xmean0, off); shift_ptr(xmean, off);
     shift_ptr(xmean_f, off); shift_ptr(pc, off); shift_ptr(psr_accum, off);
@@ -115,9 +118,12 @@ struct EventPair {
 };
 
 constexpr int kMaxPartials = 64;
-// generations per recorded graph: a long one for the bulk of a run, a short one for its tail
-// (both even: the two sorted-cost buffers alternate per generation)
-constexpr int kGensPerGraph[2] = {8, 2};
+// generations per recorded graph: long ones for the bulk of a run, a short one for its tail (all
+// even: the two sorted-cost buffers alternate per generation).  A graph starts with a sampling
+// launch of its own and ends with an update of its own, so longer graphs have fewer of both:
+// cfg2 over episodes of 100 generations, 24.2 us per generation with 8/2, 23.6 with 32/8/2.
+constexpr int kGraphKinds = 4;
+constexpr int kGensPerGraphDefault[kGraphKinds] = {32, 8, 2, 0};  // descending, even, 0 = unused
 
 }  // namespace
 
@@ -189,8 +195,9 @@ struct lmcma_hip_ctx {
     bool own_comm = false;
     int world = 0, rank = 0;
 
-    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
-    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t graph_exec[kGraphKinds] = {};
+    hipGraph_t graph[kGraphKinds] = {};
+    int graph_gens[kGraphKinds] = {};
     // two sharded generations, collectives included (lmcma_hip_run_sharded, opt-in)
     hipGraphExec_t shard_graph_exec = nullptr;
     hipGraph_t shard_graph = nullptr;
@@ -249,7 +256,7 @@ struct Arena {
 
 void drop_graph(lmcma_hip_ctx *c)
 {
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < kGraphKinds; ++q) {
         if (c->graph_exec[q]) { (void)hipGraphExecDestroy(c->graph_exec[q]); c->graph_exec[q] = nullptr; }
         if (c->graph[q]) { (void)hipGraphDestroy(c->graph[q]); c->graph[q] = nullptr; }
     }
@@ -1238,9 +1245,8 @@ int lmcma_hip_opt_reset(lmcma_hip_ctx *c)
     CTX_TRY(c);
     if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
     c->pre_done = false;
-    HIP_TRY(hipMemsetAsync(c->fused_counter, 0, sizeof(unsigned), c->stream));  // (a launch that gave up leaves it anywhere)
     hipLaunchKernelGGL(k_opt_reset, dim3(1, c->Q), dim3(256), 0, c->stream, c->opt, c->sc, c->xmean0,
-                       c->xmean, c->xmean_f, c->pc, c->N, c->ld, c->psr_accum, c->qstride);
+                       c->xmean, c->xmean_f, c->pc, c->N, c->ld, c->psr_accum, c->qstride, c->fused_counter);
     HIP_TRY(hipGetLastError());
     return LMCMA_HIP_OK;
 }
@@ -1258,7 +1264,8 @@ int lmcma_hip_opt_set_query(lmcma_hip_ctx *c, int query, const double *xmean0, d
     // that query alone goes back to its (new) initial state
     hipLaunchKernelGGL(k_opt_reset, dim3(1, 1), dim3(256), 0, c->stream, opt, query_ptr(c, c->sc, query),
                        query_ptr(c, c->xmean0, query), query_ptr(c, c->xmean, query), query_ptr(c, c->xmean_f, query),
-                       query_ptr(c, c->pc, query), c->N, c->ld, query_ptr(c, c->psr_accum, query), (size_t)0);
+                       query_ptr(c, c->pc, query), c->N, c->ld, query_ptr(c, c->psr_accum, query), (size_t)0,
+                       (unsigned *)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LMCMA_HIP_OK;
@@ -1288,7 +1295,7 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
     if (use_graph && left > 0 && !c->graph_exec[0]) {
         // The graphs are recorded on the first call, whatever its length, so that no later call
         // pays for it: one eager generation first (module load and LDS attribute calls stay out
-        // of the capture), then the launches of 8 and of 2 generations are recorded.  A capture
+        // of the capture), then the launches of 32, 8 and 2 generations are recorded.  A capture
         // records only: none of the recorded generations has run, and the host-side bookkeeping
         // they went through (the buffer parity, pre_done) ends where it started.
         if (!c->warmed) {
@@ -1298,12 +1305,27 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
             c->warmed = true;
         }
         c->graph_parity = c->parity;
-        for (int q = 0; q < 2; ++q) {
-            static_assert(kGensPerGraph[0] % 2 == 0 && kGensPerGraph[1] % 2 == 0,
-                          "the sorted-cost buffers alternate per generation");
+        for (int q = 0; q < kGraphKinds; ++q) c->graph_gens[q] = kGensPerGraphDefault[q];
+        if (const char *e = getenv("LMCMA_HIP_GRAPH_GENS")) {
+            // "16,4,2": generations per recorded graph, longest first; every entry even, because the
+            // sorted-cost buffers alternate per generation and a replay must end where it started
+            int v[kGraphKinds] = {}, n = 0;
+            for (const char *p = e; *p && n < kGraphKinds;) {
+                char *end = nullptr;
+                const long g = strtol(p, &end, 10);
+                if (end == p) break;
+                v[n++] = (int)g;
+                p = *end == ',' ? end + 1 : end;
+            }
+            bool ok = n > 0;
+            for (int q = 0; q < n; ++q) ok = ok && v[q] >= 2 && v[q] <= 1024 && v[q] % 2 == 0 && (q == 0 || v[q] < v[q - 1]);
+            if (!ok) return fail(LMCMA_HIP_ERR_ARG, "LMCMA_HIP_GRAPH_GENS: a descending list of even generation counts (2..1024) is needed");
+            for (int q = 0; q < kGraphKinds; ++q) c->graph_gens[q] = v[q];
+        }
+        for (int q = 0; q < kGraphKinds && c->graph_gens[q] > 0; ++q) {
             HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             int crc = LMCMA_HIP_OK;
-            crc = generations(c, kGensPerGraph[q]);
+            crc = generations(c, c->graph_gens[q]);
             hipError_t e = hipStreamEndCapture(c->stream, &c->graph[q]);
             if (crc != LMCMA_HIP_OK) { drop_graph(c); return crc; }
             if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
@@ -1317,8 +1339,8 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
         if (rc != LMCMA_HIP_OK) return rc;
         --left;
     }
-    for (int q = 0; use_graph && q < 2; ++q)
-        for (; left >= kGensPerGraph[q]; left -= kGensPerGraph[q]) HIP_TRY(hipGraphLaunch(c->graph_exec[q], c->stream));
+    for (int q = 0; use_graph && q < kGraphKinds && c->graph_gens[q] > 0; ++q)
+        for (; left >= c->graph_gens[q]; left -= c->graph_gens[q]) HIP_TRY(hipGraphLaunch(c->graph_exec[q], c->stream));
     if (left > 0) {
         int rc = generations(c, left);
         if (rc != LMCMA_HIP_OK) return rc;
@@ -1687,6 +1709,15 @@ int lmcma_hip_row_stride(lmcma_hip_ctx *c) { return c ? c->ld : 0; }
 int lmcma_hip_synchronize(lmcma_hip_ctx *c)
 {
     CTX_TRY(c);
+    // A blocking wait returns some tens of microseconds after the stream has drained: as long as a
+    // call of a few generations.  Poll first (about a millisecond), then block.
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipSuccess) return LMCMA_HIP_OK;
+        if (e != hipErrorNotReady) HIP_TRY(e);
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1)) break;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LMCMA_HIP_OK;
 }

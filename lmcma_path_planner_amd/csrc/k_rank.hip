@@ -654,9 +654,10 @@ __global__ __launch_bounds__(kSortedThreads) void k_rank_sorted(const RankArgs r
 // j, current cost i) with j < i, over the whole population; a context counts the pairs of ITS
 // previous costs (last generation's own list, kept as keys): for its previous element y,
 // lambda - sum over all contexts of #{their current costs <= y}.  Per element that is 2 G
-// searches of 3 rounds (16 lanes probe a list 16 ways per round; the lists pass through LDS
-// once), instead of lambda compares: the work per context no longer grows with the square of
-// the population.  sorted_cost / perm receive the entries of the
+// searches, each a binary search among the list's pivots (every 16th key, in LDS) and one
+// 64-byte window of the list read by four of the element's 16 lanes, instead of lambda compares:
+// the work per context no longer grows with the square of the population, and a workgroup reads
+// lambda / 16 keys plus the windows of its 32 elements, not the lists.  sorted_cost / perm receive the entries of the
 // local candidates only; the workgroup's elite rows go to one row of block_partials.
 struct RankMergeArgs {
     const float *lists;           // [G][n_local] ascending costs of every context (the exchanged vector)
@@ -677,7 +678,8 @@ struct RankMergeArgs {
     int owners;                   // 1, or G: this launch ranks the elements of every list (see MergeArgs)
 };
 
-constexpr int kMergeChunk = 32768;  // keys in LDS at a time (128 KiB)
+constexpr int kMergeChunk = 32768;  // the largest population ranked by merging lists
+constexpr int kMergeWindowLog = 4;  // a pivot every 16 keys: one window = 4 lanes x 16 bytes
 
 // number of entries of the ascending key list s[0..n) that are below x (or_equal: at or below):
 // a binary search by one lane.  The 16 lanes of a group each take one of the searches their
@@ -696,6 +698,62 @@ __device__ __forceinline__ int count_below(const uint32_t *s, int n, uint32_t x,
     return lo;
 }
 
+// The windows of one element's searches j0 .. j0 + cnt - 1, four searches per batch (lane u of its
+// 16-lane group holds the window of search j0 + u): lanes 4 q .. 4 q + 3 read the 16 keys of the
+// window of the batch's search q, 16 bytes each; all NB loads are requested before the first is
+// used and none behind a branch (a search that does not exist or has nothing to count reads
+// window 0 of its list and adds nothing).  A window instruction of a wave thus serves 16 searches.
+struct MergeWindowArgs {
+    const float *lists;
+    int nl, G, me, j0, cnt, lane, w;
+    uint32_t mine, yprev;
+};
+
+template <int NB>
+__device__ __forceinline__ void merge_windows(const MergeWindowArgs &a, int &rank, int &at_or_below_prev)
+{
+    constexpr int LPW = 1 << (kMergeWindowLog - 2), SPB = 16 / LPW;  // lanes per window, searches per batch
+    const int sq = a.lane / LPW, sub = a.lane % LPW;
+    float4 win[NB];
+    int wu[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int u = SPB * b + sq;
+        wu[b] = __shfl(a.w, u, 16);
+        const int ju = a.j0 + (u < a.cnt ? u : 0), g = ju >= a.G ? ju - a.G : ju;
+        const int wc = wu[b] < 0 ? 0 : wu[b];
+        win[b] = reinterpret_cast<const float4 *>(a.lists + (size_t)g * a.nl + ((size_t)wc << kMergeWindowLog))[sub];
+    }
+    asm volatile("" ::: "memory");
+    // (nothing computed from a window is moved up between the requests)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(win[b].x), "+v"(win[b].y), "+v"(win[b].z), "+v"(win[b].w));
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int u = SPB * b + sq, ju = a.j0 + u;
+        const bool prev = ju >= a.G;
+        const int g = prev ? ju - a.G : ju;
+        const uint32_t x = prev ? a.yprev : a.mine;
+        const bool or_equal = prev || g < a.me;
+        // "at or below x" = "below x + 1", unless x is the largest key, which every key is at or below
+        const uint32_t t = or_equal ? x + 1u : x;
+        const bool all = or_equal && x == ~0u;
+        int n = (order_bits(win[b].x) < t) + (order_bits(win[b].y) < t) + (order_bits(win[b].z) < t) + (order_bits(win[b].w) < t);
+        n = all ? 4 : n;
+        if (sub == 0) n += wu[b] << kMergeWindowLog;
+        n = (u < a.cnt && wu[b] >= 0) ? n : 0;
+        at_or_below_prev += prev ? n : 0;
+        rank += prev ? 0 : n;
+    }
+}
+
+// doubles of LDS for the partial sums of the elite rows: one padded row per row group
+__host__ __device__ inline size_t merge_part_doubles(int TB, int ld)
+{
+    const int c4 = ld >> 2, cw4 = c4 < TB ? c4 : TB;
+    return (size_t)(TB / cw4) * ld;
+}
+
 template <int TB>
 __global__ __launch_bounds__(TB) void k_rank_merge(const RankMergeArgs r)
 {
@@ -711,64 +769,74 @@ __global__ __launch_bounds__(TB) void k_rank_merge(const RankMergeArgs r)
     const int bx = r.owners > 1 ? (int)blockIdx.x % bpl : (int)blockIdx.x;
     const size_t own0 = r.owners > 1 ? (size_t)me * nl : 0;  // where list `me` starts in the per-owner arrays
 
-    double *s_part = s_dyn;                               // [rg][N]
-    double *s_w = s_part + (((TB > N ? TB : N) + 1) & ~1);  // [CPB]
-    int *s_cand = reinterpret_cast<int *>(s_w + CPB);     // [CPB] local candidate of each element
-    uint32_t *s_below = reinterpret_cast<uint32_t *>(s_cand + CPB);  // [TB / 64]
-    uint32_t *s_key = s_below + 16;                       // [min(lambda, kMergeChunk)]
+    double *s_part = s_dyn;                               // [row groups][ld]
+    int *s_rank = reinterpret_cast<int *>(s_part + merge_part_doubles(TB, r.ld));  // [CPB] global rank of each element
+    int *s_cand = s_rank + CPB;                           // [CPB] local candidate of each element
+    uint32_t *s_below = reinterpret_cast<uint32_t *>(s_cand + CPB);  // [TB / 64], then the elite mask
+    uint32_t *s_elite = s_below + 15;                     // bit c: element c of the workgroup is an elite
+    uint32_t *s_key = s_below + 16;                       // [G][n_local / 16] pivots
+    if (tid == 0) *s_elite = 0u;                          // (a barrier follows before the first use)
 
 #ifdef LMCMA_DIAG
     unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
 #endif
     RANK_STAMP(0);
-    const int p = bx * CPB + grp;                         // local position of this group's element
+    // A workgroup takes CPB / 2 positions from the low end of its list and the mirrored CPB / 2
+    // from the high end: the elites are the low positions of every list, and this way every
+    // workgroup adds up about the same number of elite rows.  n_local is a multiple of CPB.
+    static_assert(CPB <= 32 && CPB % 2 == 0, "one mask word per workgroup");
+    const int p = grp < CPB / 2 ? bx * (CPB / 2) + grp : nl - (bx + 1) * (CPB / 2) + (grp - CPB / 2);
     const bool live = p < nl;
     const int pc = live ? p : nl - 1;
     const uint32_t mine = order_bits(r.lists[(size_t)me * nl + pc]);
     const uint32_t yprev = psr ? r.prev_own[own0 + pc] : 0u;
     const int cand = r.local_perm[own0 + pc];
 
-    const int lists_per_chunk = kMergeChunk / nl > 0 ? kMergeChunk / nl : 1;  // n_local <= kMergeChunk
-    int rank = lane == 0 ? pc : 0, at_or_below_prev = 0;  // summed over the group's lanes after the searches
-    uint32_t kmin = ~0u;
-    {
-        for (int g0 = 0; g0 < G; g0 += lists_per_chunk) {
-            const int ng = G - g0 < lists_per_chunk ? G - g0 : lists_per_chunk;
-            const int n4 = (ng * nl + 3) >> 2, base4 = (g0 * nl) >> 2;  // n_local is a multiple of 4
-            __syncthreads();  // the previous chunk has been searched
-            constexpr int kInFlight = TB <= 512 ? 16 : 8;  // 16-byte loads per thread before the first wait
-            for (int t0 = tid; t0 < n4; t0 += kInFlight * TB) {
-                float4 c[kInFlight];
+    // ---- every 16th key of every list (a list's pivots) to LDS: lambda / 16 scattered 4-byte reads
+    const int np = nl >> kMergeWindowLog;                 // n_local is a multiple of the window
+    for (int t0 = tid; t0 < G * np; t0 += 4 * TB) {
+        float pv[4];
 #pragma unroll
-                for (int u = 0; u < kInFlight; ++u) {
-                    const int t = t0 + u * TB;
-                    c[u] = reinterpret_cast<const float4 *>(r.lists)[base4 + (t < n4 ? t : n4 - 1)];
-                }
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int u = 0; u < kInFlight; ++u) {
-                    const int t = t0 + u * TB;
-                    if (t < n4)
-                        reinterpret_cast<uint4 *>(s_key)[t] =
-                            make_uint4(order_bits(c[u].x), order_bits(c[u].y), order_bits(c[u].z), order_bits(c[u].w));
-                }
-            }
-            __syncthreads();
-            RANK_STAMP(1);
-            if (blockIdx.x == 0 && tid == 0)
-                for (int g = 0; g < ng; ++g) kmin = min(kmin, s_key[(size_t)g * nl]);  // a list's first entry is its lowest
-            // searches of this element in the chunk: its own cost in every other list (ties across
-            // contexts resolve by context order: lists before this context's count their equal keys),
-            // and, for the success rule, its previous cost in every list; lane j takes searches j, j + 16, ...
-            const int nsearch = psr ? 2 * ng : ng;
-            for (int j = lane; j < nsearch; j += 16) {
-                const bool prev = j >= ng;
-                const int gl = prev ? j - ng : j, g = g0 + gl;
-                const uint32_t *s = s_key + (size_t)gl * nl;
-                if (prev) at_or_below_prev += count_below(s, nl, yprev, true);
-                else if (g != me) rank += count_below(s, nl, mine, g < me);
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * TB < G * np ? t0 + u * TB : tid;
+            const int g = t / np, j = t - g * np;
+            pv[u] = r.lists[(size_t)g * nl + ((size_t)j << kMergeWindowLog)];
         }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (t0 + u * TB < G * np) s_key[t0 + u * TB] = order_bits(pv[u]);
+    }
+    __syncthreads();
+    RANK_STAMP(1);
+    uint32_t kmin = ~0u;
+    if (blockIdx.x == 0 && tid == 0)
+        for (int g = 0; g < G; ++g) kmin = min(kmin, s_key[(size_t)g * np]);  // a list's first entry is its lowest
+    // Searches of this element: its own cost in every other list (ties across contexts resolve by
+    // context order: lists before this context's count their equal keys), and, for the success
+    // rule, its previous cost in every list.  Lane j takes search j among the pivots: with c pivots
+    // below x (at or below), every key before window c - 1 is below x and none after it is, so the
+    // count is 16 (c - 1) + the keys of that one window below x.  The group then reads the windows
+    // of up to 16 searches, four at a time.
+    int rank = lane == 0 ? pc : 0, at_or_below_prev = 0;  // summed over the group's lanes afterwards
+    const int nsearch = psr ? 2 * G : G;
+    for (int j0 = 0; j0 < nsearch; j0 += 16) {
+        const int j = j0 + lane;
+        int w = -1;                                       // window of lane's search; -1: nothing to count
+        if (j < nsearch) {
+            const bool prev = j >= G;
+            const int g = prev ? j - G : j;
+            if (prev || g != me)
+                w = count_below(s_key + (size_t)g * np, np, prev ? yprev : mine, prev || g < me) - 1;
+        }
+        const int cnt = nsearch - j0;
+        RANK_STAMP(5);
+        const MergeWindowArgs wa{r.lists, nl, G, me, j0, cnt, lane, w, mine, yprev};
+        constexpr int SPB = 64 >> kMergeWindowLog;        // searches per batch of window reads
+        if (cnt <= SPB) merge_windows<1>(wa, rank, at_or_below_prev);
+        else if (cnt <= 2 * SPB) merge_windows<2>(wa, rank, at_or_below_prev);
+        else if (cnt <= 4 * SPB) merge_windows<4>(wa, rank, at_or_below_prev);
+        else merge_windows<16 / SPB>(wa, rank, at_or_below_prev);
     }
     // every lane of the group gets the sums over its 16 lanes
     rank = (int)row16_sum_u32((uint32_t)rank);
@@ -780,8 +848,10 @@ __global__ __launch_bounds__(TB) void k_rank_merge(const RankMergeArgs r)
     bsum = add_lane_xor32(add_lane_xor16(bsum));
     if (wl == 0) s_below[tid >> 6] = bsum;
     if (lane == 0) {
-        s_w[grp] = (live && rank < r.mu) ? r.weights[rank] : 0.0;
+        const bool elite = live && rank < r.mu;
+        s_rank[grp] = rank;
         s_cand[grp] = cand;
+        if (elite) atomicOr(s_elite, 1u << grp);
     }
     __syncthreads();
     RANK_STAMP(3);
@@ -790,34 +860,52 @@ __global__ __launch_bounds__(TB) void k_rank_merge(const RankMergeArgs r)
 #pragma unroll
         for (int w = 0; w < TB / 64; ++w) below_total += s_below[w];
     }
-    // ---- elite rows of this workgroup, elements in local order
-    const RowSumPlan pl = row_sum_plan(N, TB);
-    const int ch = (CPB + pl.rg - 1) / pl.rg;
-    const int rgi = tid / pl.cw, n0 = tid % pl.cw;
-    if (rgi < pl.rg) {
-        for (int n = n0; n < N; n += pl.cw) {
-            double acc = 0.0;
-            for (int u0 = 0; u0 < ch; u0 += 8) {
-                float x[8];
+    // ---- elite rows of this workgroup, elements in local order.  A thread owns four adjacent
+    // coordinates (one 16-byte load per row) of the elites e = rgi, rgi + rg, ... of the workgroup;
+    // all its loads are requested before the first is used.
+    const int ld = r.ld, c4 = ld >> 2;                    // ld is a multiple of 4; columns N..ld-1 are padding
+    const int cw4 = c4 < TB ? c4 : TB, rg = TB / cw4;
+    const int rgi = tid / cw4, col0 = tid - rgi * cw4;
+    const uint32_t elite_mask = *s_elite;
+    const int ne = __popc(elite_mask);
+    if (rgi < rg) {
+        for (int col = col0; col < c4; col += cw4) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            uint32_t left = elite_mask;
+            for (int k = 0; k < rgi && left != 0u; ++k) left &= left - 1u;  // skip to elite number rgi
+            for (int e0 = rgi; e0 < ne; e0 += 8 * rg) {
+                float4 x[8];
                 double w[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int c = rgi * ch + u0 + u;
-                    const bool in = u0 + u < ch && c < CPB;
-                    w[u] = in ? s_w[c] : 0.0;
-                    x[u] = r.rows[(own0 + s_cand[in ? c : 0]) * r.ld + n];
+                    w[u] = 0.0;
+                    x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (left != 0u) {
+                        const int c = __ffs((int)left) - 1;
+                        w[u] = r.weights[s_rank[c]];      // (requested together with the row)
+                        x[u] = reinterpret_cast<const float4 *>(r.rows + (own0 + (size_t)s_cand[c]) * ld)[col];
+                        for (int k = 0; k < rg && left != 0u; ++k) left &= left - 1u;  // the next one of this thread
+                    }
                 }
+                asm volatile("" ::: "memory");
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (w[u] != 0.0) acc += w[u] * (double)x[u];
+                    if (w[u] != 0.0) {
+                        a0 += w[u] * (double)x[u].x;
+                        a1 += w[u] * (double)x[u].y;
+                        a2 += w[u] * (double)x[u].z;
+                        a3 += w[u] * (double)x[u].w;
+                    }
             }
-            s_part[rgi * N + n] = acc;
+            double *dst = s_part + (size_t)rgi * ld + 4 * col;
+            reinterpret_cast<double2 *>(dst)[0] = make_double2(a0, a1);
+            reinterpret_cast<double2 *>(dst)[1] = make_double2(a2, a3);
         }
     }
     __syncthreads();
     {
         double *dst = r.block_partials + (size_t)blockIdx.x * N;
-        for (int n = tid; n < N; n += TB) dst[n] = row_sums_total(s_part, N, n, pl.rg);
+        for (int n = tid; n < N; n += TB) dst[n] = row_sums_total(s_part, ld, n, rg);
     }
     if (lane == 0 && live) {
         r.sorted_cost[rank] = value;
@@ -831,7 +919,7 @@ __global__ __launch_bounds__(TB) void k_rank_merge(const RankMergeArgs r)
 #ifdef LMCMA_DIAG
     RANK_STAMP(4);
     if (tid == 0 && blockIdx.x == gridDim.x - 1)
-        for (int q = 0; q < 5; ++q) g_update_stamps[8 + q] = st[q];
+        for (int q = 0; q < 6; ++q) g_update_stamps[8 + q] = st[q];
 #endif
 }
 
@@ -839,8 +927,8 @@ template <int TB>
 hipError_t launch_rank_merge_t(hipStream_t s, const RankMergeArgs &r, int blocks)
 {
     constexpr int CPB = TB / 16;
-    const int keys = r.lambda < kMergeChunk ? r.lambda : kMergeChunk;
-    const size_t lds = ((size_t)(((TB > r.N ? TB : r.N) + 1) & ~1) + CPB) * sizeof(double) + (size_t)CPB * sizeof(int) +
+    const int keys = r.lambda >> kMergeWindowLog;  // the pivots of all lists
+    const size_t lds = merge_part_doubles(TB, r.ld) * sizeof(double) + (size_t)2 * CPB * sizeof(int) +
                        (size_t)(16 + keys) * sizeof(uint32_t);
     {
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_rank_merge<TB>), lds);

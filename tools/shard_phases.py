@@ -61,6 +61,6 @@ if "diag" in os.environ.get("LMCMA_HIP_LIB", ""):
     # the merge kernel is the last ranking launch of a generation: its stamps are the ones left
     shard.phase_local(); ctx.synchronize(); shard.phase_rank(); ctx.synchronize()
     lib.lmcma_hip_diag_stamps(ctx._h, 1, sr)
-    names = ["first loads", "stage lists", "searches", "weights", "rows + stores"]
+    names = ["own key + pivots", "pivot searches + windows", "publish", "elite rows + stores"]
     print("merge kernel (last workgroup), ns:", {names[i]: int(sr[9 + i] - sr[8 + i]) * 10 for i in range(4)})
 print("G = %d: lambda_total %d, %.1f us per generation without collectives (eager launches)" % (G, lam_total, dt * 1e6))
