@@ -207,24 +207,32 @@ def main():
         ctx.set_cov_factor(planner.cholesky(planner.covariance(prob.dims, prob.W)))
     ctx.opt_init(prob.x0, prob.sigma0 * (8.0 if args.structured_covariance else 1.0))
 
+    # An episode (one planning query: EPISODE generations from the initial state) runs on across
+    # the calls of run_steps: warm-up and timed region are stretches of the same sequence of
+    # episodes, and a reset falls where an episode ends, not where a region starts.
+    episode = [0]
     if world == 1 and args.sharded_loop:
         ctx.comm_init(hip.HipContext.comm_unique_id(), 1, 0)
 
         def run_steps(k):
             done = 0
             while done < k:
-                n = min(EPISODE, k - done)
-                ctx.opt_reset()
+                n = min(EPISODE - episode[0], k - done)
+                if episode[0] == 0:
+                    ctx.opt_reset()
                 ctx.run_sharded(n)
                 done += n
+                episode[0] = (episode[0] + n) % EPISODE
     elif world == 1:
         def run_steps(k):
             done = 0
             while done < k:
-                n = min(EPISODE, k - done)
-                ctx.opt_reset()
+                n = min(EPISODE - episode[0], k - done)
+                if episode[0] == 0:
+                    ctx.opt_reset()
                 ctx.run(n)
                 done += n
+                episode[0] = (episode[0] + n) % EPISODE
     elif native:
         # one RCCL communicator of the library's own: rank 0 makes the id, torch.distributed carries it
         uid = [hip.HipContext.comm_unique_id() if rank == 0 else None]
@@ -234,18 +242,21 @@ def main():
         def run_steps(k):
             done = 0
             while done < k:
-                n = min(EPISODE, k - done)
-                ctx.opt_reset()
+                n = min(EPISODE - episode[0], k - done)
+                if episode[0] == 0:
+                    ctx.opt_reset()
                 ctx.run_sharded(n)
                 done += n
+                episode[0] = (episode[0] + n) % EPISODE
     else:
         shard = shard_mod.HipShard(ctx, device)
 
         def run_steps(k):
             for g in range(k):
-                if g % EPISODE == 0:
+                if episode[0] == 0:
                     ctx.opt_reset()
                 shard_mod.sharded_generation(shard)
+                episode[0] = (episode[0] + 1) % EPISODE
 
     def fence():
         if world > 1:

@@ -118,12 +118,14 @@ struct EventPair {
 };
 
 constexpr int kMaxPartials = 64;
-// generations per recorded graph: long ones for the bulk of a run, a short one for its tail (all
-// even: the two sorted-cost buffers alternate per generation).  A graph starts with a sampling
-// launch of its own and ends with an update of its own, so longer graphs have fewer of both:
-// cfg2 over episodes of 100 generations, 24.2 us per generation with 8/2, 23.6 with 32/8/2.
+// generations per recorded graph: long ones for the bulk of a run, short ones for its tail.  A
+// graph starts with a sampling launch of its own and ends with an update of its own, so longer
+// graphs have fewer of both: cfg2 over episodes of 100 generations, 24.2 us per generation with
+// 8/2, 23.6 with 32/8/2.  The two sorted-cost buffers alternate per generation, so every length
+// is recorded twice, once per buffer the first generation may find current; with a graph of one
+// generation among them a call of any length is replay only.
 constexpr int kGraphKinds = 4;
-constexpr int kGensPerGraphDefault[kGraphKinds] = {32, 8, 2, 0};  // descending, even, 0 = unused
+constexpr int kGensPerGraphDefault[kGraphKinds] = {32, 8, 2, 1};  // descending, 0 = unused
 
 }  // namespace
 
@@ -140,7 +142,7 @@ struct lmcma_hip_ctx {
     float *rows = nullptr, *zbuf = nullptr, *cost_all = nullptr, *terms = nullptr;
     float *sorted_cost = nullptr;            // = sorted_buf[parity], this generation's ascending costs
     float *sorted_buf[2] = {nullptr, nullptr};
-    int parity = 0, graph_parity = 0;
+    int parity = 0;
     bool warmed = false;
     unsigned long long *psr_accum = nullptr;
     // A shard of a population that is exchanged as sorted lists (rank_merge_possible): the local
@@ -195,8 +197,8 @@ struct lmcma_hip_ctx {
     bool own_comm = false;
     int world = 0, rank = 0;
 
-    hipGraphExec_t graph_exec[kGraphKinds] = {};
-    hipGraph_t graph[kGraphKinds] = {};
+    hipGraphExec_t graph_exec[2][kGraphKinds] = {};  // [buffer parity at the start][length]
+    hipGraph_t graph[2][kGraphKinds] = {};
     int graph_gens[kGraphKinds] = {};
     // two sharded generations, collectives included (lmcma_hip_run_sharded, opt-in)
     hipGraphExec_t shard_graph_exec = nullptr;
@@ -256,9 +258,11 @@ struct Arena {
 
 void drop_graph(lmcma_hip_ctx *c)
 {
-    for (int q = 0; q < kGraphKinds; ++q) {
-        if (c->graph_exec[q]) { (void)hipGraphExecDestroy(c->graph_exec[q]); c->graph_exec[q] = nullptr; }
-        if (c->graph[q]) { (void)hipGraphDestroy(c->graph[q]); c->graph[q] = nullptr; }
+    for (int q = 0; q < 2 * kGraphKinds; ++q) {
+        hipGraphExec_t &ge = c->graph_exec[q / kGraphKinds][q % kGraphKinds];
+        hipGraph_t &gr = c->graph[q / kGraphKinds][q % kGraphKinds];
+        if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
+        if (gr) { (void)hipGraphDestroy(gr); gr = nullptr; }
     }
     if (c->shard_graph_exec) { (void)hipGraphExecDestroy(c->shard_graph_exec); c->shard_graph_exec = nullptr; }
     if (c->shard_graph) { (void)hipGraphDestroy(c->shard_graph); c->shard_graph = nullptr; }
@@ -1292,23 +1296,22 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
     if (n_generations < 0) return fail(LMCMA_HIP_ERR_ARG, "negative generation count");
     int left = n_generations;
     const bool use_graph = !c->timing && getenv("LMCMA_HIP_NO_GRAPH") == nullptr;
-    if (use_graph && left > 0 && !c->graph_exec[0]) {
+    if (use_graph && left > 0 && !c->graph_exec[0][0]) {
         // The graphs are recorded on the first call, whatever its length, so that no later call
         // pays for it: one eager generation first (module load and LDS attribute calls stay out
-        // of the capture), then the launches of 32, 8 and 2 generations are recorded.  A capture
-        // records only: none of the recorded generations has run, and the host-side bookkeeping
-        // they went through (the buffer parity, pre_done) ends where it started.
+        // of the capture), then launches of 32, 8, 2 and 1 generations are recorded, each for both
+        // sorted-cost buffers the first of its generations may find current.  A capture records
+        // only: none of the recorded generations has run, and the host-side bookkeeping they went
+        // through (the buffer parity, pre_done) is put back to where it was.
         if (!c->warmed) {
             int rc = one_generation(c);
             if (rc != LMCMA_HIP_OK) return rc;
             --left;
             c->warmed = true;
         }
-        c->graph_parity = c->parity;
         for (int q = 0; q < kGraphKinds; ++q) c->graph_gens[q] = kGensPerGraphDefault[q];
         if (const char *e = getenv("LMCMA_HIP_GRAPH_GENS")) {
-            // "16,4,2": generations per recorded graph, longest first; every entry even, because the
-            // sorted-cost buffers alternate per generation and a replay must end where it started
+            // "16,4,1": generations per recorded graph, longest first
             int v[kGraphKinds] = {}, n = 0;
             for (const char *p = e; *p && n < kGraphKinds;) {
                 char *end = nullptr;
@@ -1318,29 +1321,38 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
                 p = *end == ',' ? end + 1 : end;
             }
             bool ok = n > 0;
-            for (int q = 0; q < n; ++q) ok = ok && v[q] >= 2 && v[q] <= 1024 && v[q] % 2 == 0 && (q == 0 || v[q] < v[q - 1]);
-            if (!ok) return fail(LMCMA_HIP_ERR_ARG, "LMCMA_HIP_GRAPH_GENS: a descending list of even generation counts (2..1024) is needed");
+            for (int q = 0; q < n; ++q) ok = ok && v[q] >= 1 && v[q] <= 1024 && (q == 0 || v[q] < v[q - 1]);
+            if (!ok) return fail(LMCMA_HIP_ERR_ARG, "LMCMA_HIP_GRAPH_GENS: a descending list of generation counts (1..1024) is needed");
             for (int q = 0; q < kGraphKinds; ++q) c->graph_gens[q] = v[q];
         }
-        for (int q = 0; q < kGraphKinds && c->graph_gens[q] > 0; ++q) {
-            HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            int crc = LMCMA_HIP_OK;
-            crc = generations(c, c->graph_gens[q]);
-            hipError_t e = hipStreamEndCapture(c->stream, &c->graph[q]);
-            if (crc != LMCMA_HIP_OK) { drop_graph(c); return crc; }
-            if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
-            e = hipGraphInstantiate(&c->graph_exec[q], c->graph[q], nullptr, nullptr, 0);
-            if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+        const int parity0 = c->parity;
+        const bool pre0 = c->pre_done;
+        for (int sp = 0; sp < 2; ++sp) {
+            for (int q = 0; q < kGraphKinds && c->graph_gens[q] > 0; ++q) {
+                c->parity = sp;
+                c->sorted_cost = c->sorted_buf[sp];
+                c->pre_done = pre0;
+                HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                const int crc = generations(c, c->graph_gens[q]);
+                hipError_t e = hipStreamEndCapture(c->stream, &c->graph[sp][q]);
+                c->parity = parity0;
+                c->sorted_cost = c->sorted_buf[parity0];
+                c->pre_done = pre0;
+                if (crc != LMCMA_HIP_OK) { drop_graph(c); return crc; }
+                if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
+                e = hipGraphInstantiate(&c->graph_exec[sp][q], c->graph[sp][q], nullptr, nullptr, 0);
+                if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+            }
         }
     }
-    if (use_graph && left > 0 && c->parity != c->graph_parity) {
-        // the graphs were recorded starting from the other sorted-cost buffer: step once eagerly
-        int rc = one_generation(c);
-        if (rc != LMCMA_HIP_OK) return rc;
-        --left;
-    }
     for (int q = 0; use_graph && q < kGraphKinds && c->graph_gens[q] > 0; ++q)
-        for (; left >= c->graph_gens[q]; left -= c->graph_gens[q]) HIP_TRY(hipGraphLaunch(c->graph_exec[q], c->stream));
+        for (; left >= c->graph_gens[q]; left -= c->graph_gens[q]) {
+            HIP_TRY(hipGraphLaunch(c->graph_exec[c->parity][q], c->stream));
+            if (c->graph_gens[q] & 1) {  // an odd number of generations leaves the other buffer current
+                c->parity ^= 1;
+                c->sorted_cost = c->sorted_buf[c->parity];
+            }
+        }
     if (left > 0) {
         int rc = generations(c, left);
         if (rc != LMCMA_HIP_OK) return rc;

@@ -444,7 +444,12 @@ def test_graph_run_equals_phase_by_phase_run(hip, lam, m):
         ctx.set_bounds(prob.lo, prob.hi)
         ctx.opt_init(prob.x0, prob.sigma0)
         if mode == "run":
-            ctx.run(27)      # 1 eager + 3 graph replays of 8 + 2 eager
+            # the first call: one eager generation, then recorded graphs of 8, 2 and 1 generations;
+            # the odd calls after it start from either of the two alternating sorted-cost buffers
+            ctx.run(12)
+            ctx.run(1)
+            ctx.run(3)
+            ctx.run(11)
         else:
             for _ in range(27):
                 ctx.phase_local()

@@ -5,7 +5,7 @@ set -o pipefail
 tag=${1:-gl}
 out=gpurun_out
 mkdir -p $out
-for g in default 16,4,2 32,8,2 100,20,4,2; do
+for g in default 8,2 32,8,2 100,20,4,1; do
   if [ $g = default ]; then unset LMCMA_HIP_GRAPH_GENS; else export LMCMA_HIP_GRAPH_GENS=$g; fi
   for a in "--steps 2000 --warmup 100" "--steps 20 --warmup 5" "--steps 20 --warmup 5"; do
     timeout -k 10 120 python3 bench.py $a --no-cpu-baseline --batched-queries 0 > $out/${tag}_tmp.json 2>> $out/${tag}_err.log || exit 1
