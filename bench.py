@@ -138,6 +138,23 @@ def host_threads():
     return max(1, min(n, 16))
 
 
+class stdout_to_stderr:
+    """RCCL writes a version banner to file descriptor 1 when its first communicator comes up;
+    the one line this program owes its caller on stdout is the JSON record, so communicators are
+    made with descriptor 1 pointing at stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,10 +198,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(args.backend)
+        with stdout_to_stderr():
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group(args.backend)
 
     prob = grids.benchmark_problem(args.config)
     lam_local = prob.lam if args.config <= 3 else prob.lam // 8   # cfg4/5 are quoted as 8-GPU populations
@@ -212,7 +230,8 @@ def main():
     # episodes, and a reset falls where an episode ends, not where a region starts.
     episode = [0]
     if world == 1 and args.sharded_loop:
-        ctx.comm_init(hip.HipContext.comm_unique_id(), 1, 0)
+        with stdout_to_stderr():
+            ctx.comm_init(hip.HipContext.comm_unique_id(), 1, 0)
 
         def run_steps(k):
             done = 0
@@ -235,9 +254,10 @@ def main():
                 episode[0] = (episode[0] + n) % EPISODE
     elif native:
         # one RCCL communicator of the library's own: rank 0 makes the id, torch.distributed carries it
-        uid = [hip.HipContext.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0], world, rank)
+        with stdout_to_stderr():
+            uid = [hip.HipContext.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(uid[0], world, rank)
 
         def run_steps(k):
             done = 0
@@ -266,10 +286,11 @@ def main():
 
     # Outside every timed region, whatever --warmup is: the library records its HIP graphs on the
     # first run call (one eager generation, then the captures), modules load, LDS limits are raised.
-    run_steps(12)
-    fence()
-    run_steps(args.warmup)
-    fence()
+    with stdout_to_stderr():    # (torch.distributed brings its communicator up at the first barrier)
+        run_steps(12)
+        fence()
+        run_steps(args.warmup)
+        fence()
     t0 = time.perf_counter()
     ctx.stream_mark(0)
     run_steps(args.steps)

@@ -1360,21 +1360,29 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
     return LMCMA_HIP_OK;
 }
 
-int lmcma_hip_phase_local(lmcma_hip_ctx *c)
+namespace {
+
+int phase_local_checks(lmcma_hip_ctx *c)
 {
-    CTX_TRY(c);
     if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
     if (!c->grid) return fail(LMCMA_HIP_ERR_STATE, "set_grid must come first");
     if (c->cfg.z_source != LMCMA_Z_PHILOX) return fail(LMCMA_HIP_ERR_STATE, "phases need z_source PHILOX");
-    int rc;
-    if (c->fused) {
-        rc = do_generate(c);
-    } else {
-        rc = do_sample(c, nullptr);
-        if (rc == LMCMA_HIP_OK) rc = do_evaluate(c);
-    }
-    if (rc != LMCMA_HIP_OK || !c->merge_protocol) return rc;
-    // a shard exchanges its costs in ascending order: rank the local candidates among themselves
+    return LMCMA_HIP_OK;
+}
+
+// sample + score the local candidates
+int local_generate(lmcma_hip_ctx *c)
+{
+    if (c->fused) return do_generate(c);
+    int rc = do_sample(c, nullptr);
+    if (rc == LMCMA_HIP_OK) rc = do_evaluate(c);
+    return rc;
+}
+
+// a shard exchanges its costs in ascending order: rank the local candidates among themselves
+int local_rank(lmcma_hip_ctx *c)
+{
+    if (!c->merge_protocol) return LMCMA_HIP_OK;
     Timed tm(c, LMCMA_K_SELECT);
     SelectArgs a{};
     a.cost_all = c->cost_raw;
@@ -1389,6 +1397,17 @@ int lmcma_hip_phase_local(lmcma_hip_ctx *c)
     HIP_TRY(launch_select(c->stream, a, &res));
     if (res.pre_done) c->pre_done = true;
     return LMCMA_HIP_OK;
+}
+
+}  // namespace
+
+int lmcma_hip_phase_local(lmcma_hip_ctx *c)
+{
+    CTX_TRY(c);
+    int rc = phase_local_checks(c);
+    if (rc == LMCMA_HIP_OK) rc = local_generate(c);
+    if (rc == LMCMA_HIP_OK) rc = local_rank(c);
+    return rc;
 }
 
 int lmcma_hip_phase_rank(lmcma_hip_ctx *c)
@@ -1598,16 +1617,28 @@ int lmcma_hip_comm_destroy(lmcma_hip_ctx *c)
 
 namespace {
 
-int sharded_generation(lmcma_hip_ctx *c, const RcclApi *api)
+// One generation of a shard.  update_due: the update of the generation before has not run yet (the
+// gathered rows are in partial_all): it runs at the head of this generation's sampling launch
+// where that form exists, as between two generations of lmcma_hip_run, else as a launch of its
+// own first.  leave_update: this generation's update is left to the next call of this function.
+int sharded_generation(lmcma_hip_ctx *c, const RcclApi *api, bool update_due = false, bool leave_update = false)
 {
     const int row = c->N + 2;
-    int rc = lmcma_hip_phase_local(c);
+    int rc = phase_local_checks(c);
     if (rc != LMCMA_HIP_OK) return rc;
+    bool carried = false;
+    if (update_due) {
+        const UpdateArgs post = update_args(c, c->partial_all, c->world, true);
+        if (c->fused && (rc = do_generate(c, &post, &carried)) != LMCMA_HIP_OK) return rc;
+        if (!carried && (rc = do_update(c, c->partial_all, c->world, true)) != LMCMA_HIP_OK) return rc;
+    }
+    if (!carried && (rc = local_generate(c)) != LMCMA_HIP_OK) return rc;
+    if ((rc = local_rank(c)) != LMCMA_HIP_OK) return rc;
     // in place: this shard's block lies at its offset inside the buffer of all costs
     RCCL_TRY(api, api->AllGather(c->cost_all + c->first, c->cost_all, (size_t)c->nloc, ncclFloat32, c->comm, c->stream));
     if ((rc = lmcma_hip_phase_rank(c)) != LMCMA_HIP_OK) return rc;
     RCCL_TRY(api, api->AllGather(c->partial_local, c->partial_all, (size_t)row, ncclFloat64, c->comm, c->stream));
-    return lmcma_hip_phase_update(c, c->world);
+    return leave_update ? LMCMA_HIP_OK : lmcma_hip_phase_update(c, c->world);
 }
 
 }  // namespace
@@ -1650,9 +1681,12 @@ int lmcma_hip_run_sharded(lmcma_hip_ctx *c, int n_generations)
         }
         for (; left >= 2; left -= 2) HIP_TRY(hipGraphLaunch(c->shard_graph_exec, c->stream));
     }
-    for (; left > 0; --left) {
-        int rc = sharded_generation(c, api);
+    // inside the call a generation's update rides with the next generation's sampling launch; the
+    // last one's is a launch of its own, so the state is complete when the call's work has finished
+    for (bool due = false; left > 0; --left) {
+        int rc = sharded_generation(c, api, due, left > 1);
         if (rc != LMCMA_HIP_OK) return rc;
+        due = true;
     }
     return LMCMA_HIP_OK;
 }
