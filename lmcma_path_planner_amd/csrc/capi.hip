@@ -125,6 +125,7 @@ constexpr int kMaxPartials = 64;
 // is recorded twice, once per buffer the first generation may find current; with a graph of one
 // generation among them a call of any length is replay only.
 constexpr int kGraphKinds = 4;
+constexpr int kCallGraphs = 4, kCallGraphMaxGens = 256;
 constexpr int kGensPerGraphDefault[kGraphKinds] = {32, 8, 2, 1};  // descending, 0 = unused
 
 }  // namespace
@@ -200,6 +201,13 @@ struct lmcma_hip_ctx {
     hipGraphExec_t graph_exec[2][kGraphKinds] = {};  // [buffer parity at the start][length]
     hipGraph_t graph[2][kGraphKinds] = {};
     int graph_gens[kGraphKinds] = {};
+    // graphs of whole calls: a call length that is none of the above gets a graph of its own,
+    // recorded behind the first call of that length, which later calls of that length replay
+    struct CallGraph {
+        int gens = 0, parity = 0;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+    } call_graph[kCallGraphs];
     // two sharded generations, collectives included (lmcma_hip_run_sharded, opt-in)
     hipGraphExec_t shard_graph_exec = nullptr;
     hipGraph_t shard_graph = nullptr;
@@ -263,6 +271,11 @@ void drop_graph(lmcma_hip_ctx *c)
         hipGraph_t &gr = c->graph[q / kGraphKinds][q % kGraphKinds];
         if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
         if (gr) { (void)hipGraphDestroy(gr); gr = nullptr; }
+    }
+    for (auto &cg : c->call_graph) {
+        if (cg.exec) (void)hipGraphExecDestroy(cg.exec);
+        if (cg.graph) (void)hipGraphDestroy(cg.graph);
+        cg = lmcma_hip_ctx::CallGraph{};
     }
     if (c->shard_graph_exec) { (void)hipGraphExecDestroy(c->shard_graph_exec); c->shard_graph_exec = nullptr; }
     if (c->shard_graph) { (void)hipGraphDestroy(c->shard_graph); c->shard_graph = nullptr; }
@@ -1285,6 +1298,32 @@ int lmcma_hip_query_select(lmcma_hip_ctx *c, int query)
 
 int lmcma_hip_queries(lmcma_hip_ctx *c) { return c ? c->Q : 0; }
 
+namespace {
+
+// Records `gens` generations, the first of which finds sorted-cost buffer `parity` current, into a
+// graph.  A capture records only: none of the recorded generations has run, and the host-side
+// bookkeeping they went through (the buffer parity, pre_done) is put back to where it was.
+int record_generations(lmcma_hip_ctx *c, int gens, int parity, hipGraph_t *graph, hipGraphExec_t *exec)
+{
+    const int parity0 = c->parity;
+    const bool pre0 = c->pre_done;
+    c->parity = parity;
+    c->sorted_cost = c->sorted_buf[parity];
+    HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    const int crc = generations(c, gens);
+    hipError_t e = hipStreamEndCapture(c->stream, graph);
+    c->parity = parity0;
+    c->sorted_cost = c->sorted_buf[parity0];
+    c->pre_done = pre0;
+    if (crc != LMCMA_HIP_OK) return crc;
+    if (e != hipSuccess) return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    e = hipGraphInstantiate(exec, *graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    return LMCMA_HIP_OK;
+}
+
+}  // namespace
+
 int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
 {
     CTX_TRY(c);
@@ -1325,26 +1364,23 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
             if (!ok) return fail(LMCMA_HIP_ERR_ARG, "LMCMA_HIP_GRAPH_GENS: a descending list of generation counts (1..1024) is needed");
             for (int q = 0; q < kGraphKinds; ++q) c->graph_gens[q] = v[q];
         }
-        const int parity0 = c->parity;
-        const bool pre0 = c->pre_done;
-        for (int sp = 0; sp < 2; ++sp) {
+        for (int sp = 0; sp < 2; ++sp)
             for (int q = 0; q < kGraphKinds && c->graph_gens[q] > 0; ++q) {
-                c->parity = sp;
-                c->sorted_cost = c->sorted_buf[sp];
-                c->pre_done = pre0;
-                HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-                const int crc = generations(c, c->graph_gens[q]);
-                hipError_t e = hipStreamEndCapture(c->stream, &c->graph[sp][q]);
-                c->parity = parity0;
-                c->sorted_cost = c->sorted_buf[parity0];
-                c->pre_done = pre0;
-                if (crc != LMCMA_HIP_OK) { drop_graph(c); return crc; }
-                if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
-                e = hipGraphInstantiate(&c->graph_exec[sp][q], c->graph[sp][q], nullptr, nullptr, 0);
-                if (e != hipSuccess) { drop_graph(c); return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+                const int rc = record_generations(c, c->graph_gens[q], sp, &c->graph[sp][q], &c->graph_exec[sp][q]);
+                if (rc != LMCMA_HIP_OK) { drop_graph(c); return rc; }
             }
-        }
     }
+    // a call whose whole length has a graph of its own: one launch
+    if (use_graph && left > 0 && left == n_generations)
+        for (auto &cg : c->call_graph)
+            if (cg.exec && cg.gens == left && cg.parity == c->parity) {
+                HIP_TRY(hipGraphLaunch(cg.exec, c->stream));
+                if (left & 1) {
+                    c->parity ^= 1;
+                    c->sorted_cost = c->sorted_buf[c->parity];
+                }
+                return LMCMA_HIP_OK;
+            }
     for (int q = 0; use_graph && q < kGraphKinds && c->graph_gens[q] > 0; ++q)
         for (; left >= c->graph_gens[q]; left -= c->graph_gens[q]) {
             HIP_TRY(hipGraphLaunch(c->graph_exec[c->parity][q], c->stream));
@@ -1356,6 +1392,28 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
     if (left > 0) {
         int rc = generations(c, left);
         if (rc != LMCMA_HIP_OK) return rc;
+    }
+    // A caller that steps n generations at a time tends to do so again.  A call cut into several
+    // recorded graphs pays a start and an end per piece (and the host a launch each): behind such a
+    // call, while the device is busy with it, a graph of the whole length is recorded for the
+    // buffer parity the next call will find, and calls of that length replay it from then on.
+    if (use_graph && n_generations > 2 && n_generations <= kCallGraphMaxGens) {
+        bool piece = false, have = false;
+        for (int q = 0; q < kGraphKinds; ++q) piece = piece || c->graph_gens[q] == n_generations;
+        for (auto &cg : c->call_graph) have = have || (cg.exec && cg.gens == n_generations && cg.parity == c->parity);
+        if (!piece && !have)
+            for (auto &cg : c->call_graph)
+                if (!cg.exec) {
+                    const int rc = record_generations(c, n_generations, c->parity, &cg.graph, &cg.exec);
+                    if (rc != LMCMA_HIP_OK) {
+                        if (cg.graph) (void)hipGraphDestroy(cg.graph);
+                        cg = lmcma_hip_ctx::CallGraph{};
+                        return rc;
+                    }
+                    cg.gens = n_generations;
+                    cg.parity = c->parity;
+                    break;
+                }
     }
     return LMCMA_HIP_OK;
 }

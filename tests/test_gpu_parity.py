@@ -444,14 +444,14 @@ def test_graph_run_equals_phase_by_phase_run(hip, lam, m):
         ctx.set_bounds(prob.lo, prob.hi)
         ctx.opt_init(prob.x0, prob.sigma0)
         if mode == "run":
-            # the first call: one eager generation, then recorded graphs of 8, 2 and 1 generations;
-            # the odd calls after it start from either of the two alternating sorted-cost buffers
-            ctx.run(12)
-            ctx.run(1)
-            ctx.run(3)
-            ctx.run(11)
+            # the first call: one eager generation, then recorded graphs of 32, 8, 2 and 1 generations;
+            # the odd calls after it start from either of the two alternating sorted-cost buffers;
+            # a call length seen before (3 from the other buffer, then 3 and 12 again) replays the
+            # graph of the whole call that was recorded behind its first use
+            for n in (12, 1, 3, 11, 3, 3, 12, 3):
+                ctx.run(n)
         else:
-            for _ in range(27):
+            for _ in range(48):
                 ctx.phase_local()
                 ctx.phase_rank()
                 ctx.phase_update(0)
@@ -459,7 +459,7 @@ def test_graph_run_equals_phase_by_phase_run(hip, lam, m):
         results.append(st)
         ctx.close()
     a, b = results
-    assert a["itr"] == b["itr"] == 27 and a["counteval"] == 27 * lam
+    assert a["itr"] == b["itr"] == 48 and a["counteval"] == 48 * lam
     np.testing.assert_array_equal(a["xmean"], b["xmean"])     # deterministic kernels: bit-identical
     assert a["sigma"] == b["sigma"] and a["best_f"] == b["best_f"]
 
