@@ -209,7 +209,10 @@ int lmcma_hip_opt_reset(lmcma_hip_ctx *ctx);
  * L/lmcma.cpp:426-429); here the update kernels evaluate that rule: once it has
  * fired the state is left as it is, so generations queued beyond it change
  * nothing and lmcma_hip_opt_summary.itr is the generation that reached it.
- * The first call on a context also records the HIP graphs later calls replay.
+ * The first call on a context also records the HIP graphs later calls replay
+ * (32, 8, 2 and 1 generations; a call is cut into these), and a call length that
+ * is none of them gets a graph of the whole call, recorded behind the first call
+ * of that length and replayed by later ones (up to four lengths of at most 256).
  * Inside a call the update of one generation may run at the head of the next generation's
  * sampling launch; the state in memory is complete when the call's work has finished, as with
  * the stepwise calls, and the results are the same bits.                                  */

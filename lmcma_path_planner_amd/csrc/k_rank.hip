@@ -678,7 +678,8 @@ struct RankMergeArgs {
     int owners;                   // 1, or G: this launch ranks the elements of every list (see MergeArgs)
 };
 
-constexpr int kMergeChunk = 32768;  // the largest population ranked by merging lists
+constexpr int kMergeChunk = 32768;  // the longest list; also the largest population one context ranks in tiles
+constexpr int kMergeMaxLambda = 1 << 19;  // 32768 pivots = 128 KiB of LDS
 constexpr int kMergeWindowLog = 4;  // a pivot every 16 keys: one window = 4 lanes x 16 bytes
 
 // number of entries of the ascending key list s[0..n) that are below x (or_equal: at or below):
@@ -1009,8 +1010,9 @@ int rank_tile_len(int lambda)
 
 bool rank_merge_possible(int lambda, int n_local, int first_candidate)
 {
+    // (the pivots of all lists, lambda / 16 keys, have to fit in LDS beside the row sums)
     return n_local < lambda && n_local % 64 == 0 && lambda % n_local == 0 && first_candidate % n_local == 0 &&
-           n_local <= kMergeChunk && getenv("LMCMA_HIP_NO_MERGE_RANK") == nullptr;
+           n_local <= kMergeChunk && lambda <= kMergeMaxLambda && getenv("LMCMA_HIP_NO_MERGE_RANK") == nullptr;
 }
 
 hipError_t launch_rank_merge(hipStream_t s, const MergeArgs &a, int *rows_out)
