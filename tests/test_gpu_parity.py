@@ -464,6 +464,35 @@ def test_graph_run_equals_phase_by_phase_run(hip, lam, m):
     assert a["sigma"] == b["sigma"] and a["best_f"] == b["best_f"]
 
 
+def test_more_call_lengths_than_the_library_keeps_graphs_for(hip):
+    """lmcma_hip_run keeps a graph of a whole call for four call lengths; further lengths are cut
+    into the recorded pieces every time.  Either way the state equals the phase-by-phase one."""
+    from lmcma_path_planner_amd import grids
+    prob = grids.benchmark_problem(2)
+    lam, m = 512, 16
+    lengths = (3, 3, 5, 5, 7, 7, 9, 9, 11, 11, 13, 13, 3, 13)
+    results = []
+    for mode in ("run", "phases"):
+        ctx = hip.HipContext(prob.N, lam, m, dims=2, waypoints=prob.W, start=prob.start, goal=prob.goal, seed=11)
+        ctx.set_grid(prob.occ)
+        ctx.set_bounds(prob.lo, prob.hi)
+        ctx.opt_init(prob.x0, prob.sigma0)
+        if mode == "run":
+            for n in lengths:
+                ctx.run(n)
+        else:
+            for _ in range(sum(lengths)):
+                ctx.phase_local()
+                ctx.phase_rank()
+                ctx.phase_update(0)
+        results.append(ctx.opt_get())
+        ctx.close()
+    a, b = results
+    assert a["itr"] == b["itr"] == sum(lengths)
+    np.testing.assert_array_equal(a["xmean"], b["xmean"])
+    assert a["sigma"] == b["sigma"] and a["best_f"] == b["best_f"]
+
+
 def test_stop_rule_fires_in_the_oracles_generation_and_freezes_the_state(hip, oracle):
     """LMCMA::isBehaviorLearningDone (lmcma.cpp:426-429: sigma < 1e-20) evaluated by the update
     kernel.  Float rows resolve a step size of 1e-20 only around the origin, so the problem is a
