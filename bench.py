@@ -280,9 +280,11 @@ def main():
                 episode[0] = (episode[0] + 1) % EPISODE
 
     def fence():
+        # the library's own work first: its collectives (a communicator of its own, on its own
+        # stream) have finished on this rank before torch.distributed's communicator runs the barrier
+        ctx.synchronize()
         if world > 1:
             dist.barrier()
-        ctx.synchronize()
         torch.cuda.synchronize()
 
     # Outside every timed region, whatever --warmup is: the library records its HIP graphs on the
