@@ -557,7 +557,7 @@ int do_recombine_final(lmcma_hip_ctx *c, int rows, bool with_scalars)
     // A context whose row goes into an exchange may add its rows with any (fixed) workgroup size;
     // one that feeds its own update must use the update's, so that reducing first and updating
     // from the one row gives the same bits as updating from the block rows.
-    const int threads = c->merge_protocol ? 1024 : update_threads(c->N, std::min(c->m, LMCMA_HIP_MAX_VECTORS));
+    const int threads = c->merge_protocol ? 0 : update_threads(c->N, std::min(c->m, LMCMA_HIP_MAX_VECTORS));
     HIP_TRY(launch_recombine_final(c->stream, src, rows, c->N, c->partial_local, threads,
                                    with_scalars ? &x : nullptr));
     return LMCMA_HIP_OK;

@@ -215,6 +215,8 @@ struct FinalExtras {
     int count_psr;
     const float *best;
 };
+// threads: the workgroup size whose summation order the result must have (a row that feeds the
+// context's own update: the update's); 0: any fixed order will do (a row that goes into an exchange)
 hipError_t launch_recombine_final(hipStream_t s, const double *block_partials, int rows, int N,
                                   double *partial_local, int threads, const FinalExtras *extras);
 // First level of the sum over many partial rows (k_reduce_rows): rows -> reduce_rows_out(rows) <=

@@ -82,6 +82,61 @@ __global__ __launch_bounds__(1024) void k_recombine_final(const double *__restri
     }
 }
 
+// The same sum by several workgroups, 16 columns each, for a row that leaves the context (a shard's
+// contribution to the exchange; nothing else has to reproduce its summation order): one workgroup
+// reads the freshly written rows at some tens of GB/s, N / 16 of them read a 128-byte strip each.
+// Thread (g, c) adds rows g, g + 32, ... of columns 16 b + 2 c, + 1; the 32 partial sums of a
+// column are then added in group order.  Even N.
+__global__ __launch_bounds__(256) void k_recombine_final_wide(const double *__restrict__ block_partials,
+                                                              int nblocks, int N,
+                                                              double *__restrict__ partial_local, const FinalExtras x)
+{
+    __shared__ double s_red[32][16];
+    const int tid = threadIdx.x, g = tid >> 3, c = tid & 7;
+    const int n = 16 * (int)blockIdx.x + 2 * c;
+    double a0 = 0.0, a1 = 0.0;
+    if (n < N) {
+        for (int r0 = g; r0 < nblocks; r0 += 32 * 8) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + 32 * u;
+                v[u] = make_double2(0.0, 0.0);
+                if (r < nblocks) v[u] = *reinterpret_cast<const double2 *>(block_partials + (size_t)r * N + n);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (r0 + 32 * u < nblocks) {
+                    a0 += v[u].x;
+                    a1 += v[u].y;
+                }
+        }
+    }
+    s_red[g][2 * c] = a0;
+    s_red[g][2 * c + 1] = a1;
+    __syncthreads();
+    if (tid < 16 && 16 * (int)blockIdx.x + tid < N) {
+        double total = 0.0;
+        for (int q = 0; q < 32; ++q) total += s_red[q][tid];
+        partial_local[16 * blockIdx.x + tid] = total;
+    }
+    if (blockIdx.x == 0 && x.best != nullptr && tid >= 64 && tid < 128) {
+        const int l = tid - 64;
+        unsigned long long v = 0ull;
+        if (x.count_psr) {
+            for (int b = l; b < x.n_parts; b += 64) v += x.psr_parts[b];
+            if (l == 0 && x.psr_accum != nullptr) v += *x.psr_accum;
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
+        if (l == 0) {
+            partial_local[N] = (double)v;
+            partial_local[N + 1] = (double)*x.best;
+        }
+    }
+}
+
 // A first level for many partial rows: rows [b chunk, (b + 1) chunk) of src -> row b of dst.
 // One workgroup reads freshly written rows at some tens of GB/s, so beyond a hundred rows or so
 // the single workgroup that consumes them is better off with a few dozen rows summed by
@@ -212,6 +267,14 @@ hipError_t launch_recombine_final(hipStream_t s, const double *block_partials, i
     if (rows < 1 || N < 1) return hipErrorInvalidValue;
     FinalExtras x{};
     if (extras) x = *extras;
+    if (threads == 0) {  // the caller leaves the summation order to this function
+        if ((N & 1) == 0 && rows >= 32) {
+            hipLaunchKernelGGL(k_recombine_final_wide, dim3((N + 15) / 16), dim3(256), 0, s, block_partials, rows, N,
+                               partial_local, x);
+            return hipGetLastError();
+        }
+        threads = 1024;
+    }
     hipLaunchKernelGGL(k_recombine_final, dim3(1), dim3(threads), 0, s, block_partials, rows, N, partial_local, x);
     return hipGetLastError();
 }
