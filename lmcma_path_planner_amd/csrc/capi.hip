@@ -534,7 +534,7 @@ int reduce_if_many(lmcma_hip_ctx *c, int *rows, const double **src)
     Timed tm(c, LMCMA_K_RECOMBINE);
     HIP_TRY(launch_reduce_rows(c->stream, c->block_partials, *rows, c->N, c->reduced_rows, batch_of(c)));
     *src = c->reduced_rows;
-    *rows = reduce_rows_out(*rows);
+    *rows = reduce_rows_out(*rows, c->N);
     return LMCMA_HIP_OK;
 }
 

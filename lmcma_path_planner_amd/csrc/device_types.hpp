@@ -219,11 +219,11 @@ struct FinalExtras {
 // context's own update: the update's); 0: any fixed order will do (a row that goes into an exchange)
 hipError_t launch_recombine_final(hipStream_t s, const double *block_partials, int rows, int N,
                                   double *partial_local, int threads, const FinalExtras *extras);
-// First level of the sum over many partial rows (k_reduce_rows): rows -> reduce_rows_out(rows) <=
-// kReducedRowsMax rows of dst; used above kReduceRowsFrom rows.
+// The sum over many partial rows, ahead of the update: rows -> reduce_rows_out(rows, N) <=
+// kReducedRowsMax rows of dst (one row for even N); used above kReduceRowsFrom rows.
 constexpr int kReducedRowsMax = 32;
 constexpr int kReduceRowsFrom = 192;
-int reduce_rows_out(int rows);
+int reduce_rows_out(int rows, int N);
 hipError_t launch_reduce_rows(hipStream_t s, const double *src, int rows, int N, double *dst, Batch batch);
 
 // workgroup size the update uses for m direction vectors of N parameters

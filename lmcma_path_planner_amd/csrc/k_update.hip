@@ -87,11 +87,13 @@ __global__ __launch_bounds__(1024) void k_recombine_final(const double *__restri
 // reads the freshly written rows at some tens of GB/s, N / 16 of them read a 128-byte strip each.
 // Thread (g, c) adds rows g, g + 32, ... of columns 16 b + 2 c, + 1; the 32 partial sums of a
 // column are then added in group order.  Even N.
-__global__ __launch_bounds__(256) void k_recombine_final_wide(const double *__restrict__ block_partials,
-                                                              int nblocks, int N,
-                                                              double *__restrict__ partial_local, const FinalExtras x)
+__global__ __launch_bounds__(256) void k_recombine_final_wide(const double *block_partials, int nblocks, int N,
+                                                              double *partial_local, const FinalExtras x,
+                                                              size_t qstride)
 {
     __shared__ double s_red[32][16];
+    shift_ptr(block_partials, blockIdx.y * qstride);  // query blockIdx.y of a batch
+    shift_ptr(partial_local, blockIdx.y * qstride);
     const int tid = threadIdx.x, g = tid >> 3, c = tid & 7;
     const int n = 16 * (int)blockIdx.x + 2 * c;
     double a0 = 0.0, a1 = 0.0;
@@ -246,8 +248,17 @@ hipError_t launch_recombine(hipStream_t s, const float *rows, int ld, int N, int
     return hipGetLastError();
 }
 
-int reduce_rows_out(int rows)
+// Many partial rows of even length go to ONE row (the strips of k_recombine_final_wide), so the
+// update that follows reads a single row; odd lengths keep the first level of at most 32 rows.
+static bool reduce_to_one_row(int N)
 {
+    static const bool off = getenv("LMCMA_HIP_REDUCE_TWO_LEVELS") != nullptr;
+    return !off && (N & 1) == 0;
+}
+
+int reduce_rows_out(int rows, int N)
+{
+    if (reduce_to_one_row(N)) return 1;
     const int chunk = (rows + kReducedRowsMax - 1) / kReducedRowsMax;
     return (rows + chunk - 1) / chunk;
 }
@@ -255,8 +266,13 @@ int reduce_rows_out(int rows)
 hipError_t launch_reduce_rows(hipStream_t s, const double *src, int rows, int N, double *dst, Batch batch)
 {
     if (rows < 1 || N < 1 || N > 512 || batch.queries < 1) return hipErrorInvalidValue;
+    if (reduce_to_one_row(N)) {
+        hipLaunchKernelGGL(k_recombine_final_wide, dim3((N + 15) / 16, batch.queries), dim3(256), 0, s, src, rows, N, dst,
+                           FinalExtras{}, batch.stride);
+        return hipGetLastError();
+    }
     const int chunk = (rows + kReducedRowsMax - 1) / kReducedRowsMax;
-    hipLaunchKernelGGL(k_reduce_rows, dim3(reduce_rows_out(rows), batch.queries), dim3(256), 0, s, src, rows, chunk, N,
+    hipLaunchKernelGGL(k_reduce_rows, dim3(reduce_rows_out(rows, N), batch.queries), dim3(256), 0, s, src, rows, chunk, N,
                        dst, batch.stride);
     return hipGetLastError();
 }
@@ -270,7 +286,7 @@ hipError_t launch_recombine_final(hipStream_t s, const double *block_partials, i
     if (threads == 0) {  // the caller leaves the summation order to this function
         if ((N & 1) == 0 && rows >= 32) {
             hipLaunchKernelGGL(k_recombine_final_wide, dim3((N + 15) / 16), dim3(256), 0, s, block_partials, rows, N,
-                               partial_local, x);
+                               partial_local, x, (size_t)0);
             return hipGetLastError();
         }
         threads = 1024;
