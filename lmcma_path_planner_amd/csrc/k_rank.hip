@@ -1002,8 +1002,10 @@ int rank_tile_len(int lambda)
     // above one tile of the counting rank and up to what the merge holds in LDS at once; equal tiles
     // that are whole rounds of the counting kernel
     // (up to two tiles the one-launch counting rank is faster: 11.8 us against 6.6 + 9.2 us at 8192)
-    if (lambda <= 2 * kSortTile || lambda > kMergeChunk || getenv("LMCMA_HIP_NO_TILED_RANK") != nullptr) return 0;
-    const int tiles = (lambda + kSortTile - 1) / kSortTile;
+    static const int tile = getenv("LMCMA_HIP_RANK_TILE") ? atoi(getenv("LMCMA_HIP_RANK_TILE")) : kSortTile;
+    if (tile < 256 || tile > kSortTile) return 0;
+    if (lambda <= 2 * tile || lambda > kMergeChunk || getenv("LMCMA_HIP_NO_TILED_RANK") != nullptr) return 0;
+    const int tiles = (lambda + tile - 1) / tile;
     if (lambda % tiles != 0 || (lambda / tiles) % 256 != 0) return 0;
     return lambda / tiles;
 }
