@@ -1307,9 +1307,9 @@ int record_generations(lmcma_hip_ctx *c, int gens, int parity, hipGraph_t *graph
 {
     const int parity0 = c->parity;
     const bool pre0 = c->pre_done;
+    HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     c->parity = parity;
     c->sorted_cost = c->sorted_buf[parity];
-    HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     const int crc = generations(c, gens);
     hipError_t e = hipStreamEndCapture(c->stream, graph);
     c->parity = parity0;
@@ -1404,14 +1404,15 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
         if (!piece && !have)
             for (auto &cg : c->call_graph)
                 if (!cg.exec) {
-                    const int rc = record_generations(c, n_generations, c->parity, &cg.graph, &cg.exec);
-                    if (rc != LMCMA_HIP_OK) {
+                    // (the call's own work is queued already: a graph that cannot be recorded is
+                    // done without, the call has not failed)
+                    if (record_generations(c, n_generations, c->parity, &cg.graph, &cg.exec) != LMCMA_HIP_OK) {
                         if (cg.graph) (void)hipGraphDestroy(cg.graph);
                         cg = lmcma_hip_ctx::CallGraph{};
-                        return rc;
+                    } else {
+                        cg.gens = n_generations;
+                        cg.parity = c->parity;
                     }
-                    cg.gens = n_generations;
-                    cg.parity = c->parity;
                     break;
                 }
     }
