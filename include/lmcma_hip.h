@@ -291,6 +291,38 @@ int lmcma_hip_comm_attach(lmcma_hip_ctx *ctx, void *nccl_comm, int world, int ra
 int lmcma_hip_comm_destroy(lmcma_hip_ctx *ctx);
 int lmcma_hip_run_sharded(lmcma_hip_ctx *ctx, int n_generations);
 
+/* ---- the same loop with a direct exchange between the shards (no reference counterpart) -----
+ * Two all-gathers of a few KB per generation cost their latency, not their bandwidth.  Here every
+ * shard owns a "mailbox" in fine-grained device memory that the other shards map (an IPC handle
+ * across processes, the plain pointer inside one process); a shard stores its sorted costs and
+ * its row of N + 2 doubles straight into the peers' mailboxes over xGMI and bumps an arrival
+ * counter there, and the kernels that consume them (the merge of the sorted lists, the update)
+ * wait for the counters at their head.  Bit-identical to the RCCL form.
+ *
+ * lmcma_hip_peer_handle      allocates the context's mailbox and fills `handle`; the caller hands
+ *                            the 128 bytes of every shard to every shard (as it does with the
+ *                            RCCL id)
+ * lmcma_hip_peer_connect     handles = world blobs in rank order (its own included); maps the
+ *                            peers' mailboxes.  From then on lmcma_hip_run_sharded exchanges
+ *                            directly (a communicator the context may also have is not used).
+ *                            world <= 16.  Every shard must connect before any shard runs, and
+ *                            all shards make the same run_sharded calls.
+ * lmcma_hip_peer_disconnect  unmaps; run_sharded is back to the communicator
+ * lmcma_hip_peer_status      after the context's work has finished: whether the mailbox is
+ *                            fine-grained memory, and whether a wait for a peer gave up (non-zero:
+ *                            1 + the source that did not arrive within 4 s; the state is then
+ *                            meaningless; lmcma_hip_opt_get reports it as an error too)
+ * lmcma_hip_run_sharded_group  G shards held by ONE process (ctxs[r] = shard r, on any devices):
+ *                            the loop with the two exchanges as device-to-device copies ordered
+ *                            by events between the contexts' streams.  No communicator, no
+ *                            mailbox, no kernel waits for another.                          */
+#define LMCMA_HIP_PEER_HANDLE_BYTES 128
+int lmcma_hip_peer_handle(lmcma_hip_ctx *ctx, char handle[LMCMA_HIP_PEER_HANDLE_BYTES]);
+int lmcma_hip_peer_connect(lmcma_hip_ctx *ctx, const char *handles, int world, int rank);
+int lmcma_hip_peer_disconnect(lmcma_hip_ctx *ctx);
+int lmcma_hip_peer_status(lmcma_hip_ctx *ctx, int *fine_grained, int *wait_error);
+int lmcma_hip_run_sharded_group(lmcma_hip_ctx **ctxs, int world, int n_generations);
+
 typedef struct {
     int32_t itr;          /* generations completed (L/lmcma.hpp:60)              */
     int32_t iterator_sz;  /* active direction vectors                            */

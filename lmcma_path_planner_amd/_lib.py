@@ -160,6 +160,11 @@ SIGNATURES = {
     "lmcma_hip_comm_attach": (_i, [_vp, _vp, _i, _i]),
     "lmcma_hip_comm_destroy": (_i, [_vp]),
     "lmcma_hip_run_sharded": (_i, [_vp, _i]),
+    "lmcma_hip_peer_handle": (_i, [_vp, ctypes.c_char_p]),
+    "lmcma_hip_peer_connect": (_i, [_vp, ctypes.c_char_p, _i, _i]),
+    "lmcma_hip_peer_disconnect": (_i, [_vp]),
+    "lmcma_hip_peer_status": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "lmcma_hip_run_sharded_group": (_i, [ctypes.POINTER(_vp), _i, _i]),
     "lmcma_hip_opt_get": (_i, [_vp, ctypes.POINTER(OptSummary), c_double_p]),
     "lmcma_hip_opt_get_vectors": (_i, [_vp, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                        c_int32_p]),

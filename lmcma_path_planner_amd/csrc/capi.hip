@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -197,6 +198,19 @@ struct lmcma_hip_ctx {
     ncclComm_t comm = nullptr;
     bool own_comm = false;
     int world = 0, rank = 0;
+
+    // direct exchange between the shards (lmcma_hip_peer_*): the own mailbox (fine-grained device
+    // memory the peers write into) and the peers' mailboxes as mapped here
+    void *mailbox = nullptr;
+    size_t mailbox_bytes = 0;
+    bool mailbox_fine = false, peer_on = false;
+    void *peer_base[kMaxPeerRanks] = {};
+    bool peer_ipc[kMaxPeerRanks] = {};     // mapped with hipIpcOpenMemHandle (to be closed)
+    uint32_t peer_epoch = 0;               // exchanges of each kind made so far (every shard counts alike)
+    float *arena_cost_all = nullptr;       // the arena's own buffers, current again after peer_disconnect
+    double *arena_partial_all = nullptr;
+    PeerWait wait_costs{}, wait_rows{};
+    hipEvent_t group_ev[2] = {nullptr, nullptr};   // lmcma_hip_run_sharded_group: this shard's two hand-over points
 
     hipGraphExec_t graph_exec[2][kGraphKinds] = {};  // [buffer parity at the start][length]
     hipGraph_t graph[2][kGraphKinds] = {};
@@ -441,6 +455,7 @@ UpdateArgs update_args(const lmcma_hip_ctx *c, const double *partials, int n_par
     a.t = c->t; a.vec = c->vec; a.iterator = c->iterator;
     a.xmean_f = c->xmean_f; a.V_f = c->V_f; a.B_f = c->B_f;
     a.batch = batch_of(c);
+    if (rows_with_scalars && c->peer_on && partials == c->partial_all) a.wait = c->wait_rows;
     return a;
 }
 
@@ -798,6 +813,10 @@ int lmcma_hip_destroy(lmcma_hip_ctx *c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)lmcma_hip_comm_destroy(c);
+    (void)lmcma_hip_peer_disconnect(c);
+    if (c->mailbox) (void)hipFree(c->mailbox);
+    for (hipEvent_t ev : c->group_ev)
+        if (ev) (void)hipEventDestroy(ev);
     drop_graph(c);
     for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (hipEvent_t ev : c->mark)
@@ -1494,6 +1513,7 @@ int lmcma_hip_phase_rank(lmcma_hip_ctx *c)
             a.rows = c->rows; a.ld = c->ld; a.N = c->N;
             a.weights = c->weights; a.mu = c->mu;
             a.block_partials = c->block_partials;
+            if (c->peer_on) a.wait = c->wait_costs;
             HIP_TRY(launch_rank_merge(c->stream, a, &rows));
             c->psr_parts_n = rows;
             c->ranked_local_only = true;
@@ -1669,20 +1689,122 @@ int lmcma_hip_comm_destroy(lmcma_hip_ctx *c)
     if (c->comm) drop_graph(c);   // a recorded sharded generation holds this communicator's collectives
     c->comm = nullptr;
     c->own_comm = false;
-    c->world = 0;
-    c->rank = 0;
+    if (!c->peer_on) {
+        c->world = 0;
+        c->rank = 0;
+    }
     return LMCMA_HIP_OK;
 }
 
+/* ---- sharded population: the direct exchange ------------------------------------------ */
+
 namespace {
 
-// One generation of a shard.  update_due: the update of the generation before has not run yet (the
-// gathered rows are in partial_all): it runs at the head of this generation's sampling launch
-// where that form exists, as between two generations of lmcma_hip_run, else as a launch of its
-// own first.  leave_update: this generation's update is left to the next call of this function.
-int sharded_generation(lmcma_hip_ctx *c, const RcclApi *api, bool update_due = false, bool leave_update = false)
+// A shard's block (its sorted costs, or its row of N + 2 doubles) into every mailbox of `s`.
+// Workgroup d * parts + part copies part `part` of the block to destination d, makes its stores
+// visible at system scope, and adds 1 to that destination's arrival counter: `parts` arrivals per
+// source and exchange.
+__global__ __launch_bounds__(256) void k_peer_push(const PeerSend s, const uint32_t *__restrict__ src, int words, int parts)
 {
+    const int tid = threadIdx.x;
+    const int d = (int)blockIdx.x / parts, part = (int)blockIdx.x - d * parts;
+    const int per = (((words + parts - 1) / parts) + 3) & ~3;  // words per part, whole 16-byte units
+    const int w0 = part * per, w1 = min(words, w0 + per);
+    uint32_t *dst = static_cast<uint32_t *>(s.dst[d]);
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const int quads = w1 > w0 ? (w1 - w0) >> 2 : 0;
+        for (int q = tid; q < quads; q += 256)
+            reinterpret_cast<uint4 *>(dst + w0)[q] = reinterpret_cast<const uint4 *>(src + w0)[q];
+        for (int w = w0 + 4 * quads + tid; w < w1; w += 256) dst[w] = src[w];
+    } else {
+        for (int w = w0 + tid; w < w1; w += 256) dst[w] = src[w];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0 && s.flag[d] != nullptr)
+        __hip_atomic_fetch_add(s.flag[d], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// layout of a mailbox (the same in every shard of a population: it depends on lambda and N only)
+constexpr size_t kMailboxFlagBytes = 1024;   // [0, 64) cost counters, [64, 128) row counters, [128] error word
+constexpr int kMailboxRowFlags = 64, kMailboxError = 128;
+constexpr int kCostParts = 4;                // workgroups (arrivals) per destination of the cost exchange
+
+size_t mailbox_cost_offset() { return kMailboxFlagBytes; }
+size_t mailbox_rows_offset(int lambda) { return kMailboxFlagBytes + (((size_t)lambda * sizeof(float) + 16 + 255) & ~(size_t)255); }
+size_t mailbox_total(int lambda, int N) { return mailbox_rows_offset(lambda) + (size_t)kMaxPeerRanks * (N + 2) * sizeof(double) + 256; }
+
+struct PeerHandle {
+    uint32_t magic;
+    int32_t pid, device, fine;
+    uint64_t ptr, bytes;
+    int32_t lambda, N;
+    hipIpcMemHandle_t ipc;
+};
+static_assert(sizeof(PeerHandle) <= LMCMA_HIP_PEER_HANDLE_BYTES, "the handle blob holds a PeerHandle");
+constexpr uint32_t kPeerMagic = 0x4c4d5058u;
+
+uint32_t *mailbox_flags(void *base) { return static_cast<uint32_t *>(base); }
+float *mailbox_cost(void *base) { return reinterpret_cast<float *>(static_cast<char *>(base) + mailbox_cost_offset()); }
+double *mailbox_rows(void *base, int lambda)
+{
+    return reinterpret_cast<double *>(static_cast<char *>(base) + mailbox_rows_offset(lambda));
+}
+
+int ensure_mailbox(lmcma_hip_ctx *c)
+{
+    if (c->mailbox) return LMCMA_HIP_OK;
+    const size_t bytes = mailbox_total(c->lambda, c->N);
+    void *p = nullptr;
+    // fine-grained: stores of a peer become visible to this device's kernels while they run
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+    c->mailbox_fine = e == hipSuccess;
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_TRY(hipMalloc(&p, bytes));
+    }
+    HIP_TRY(hipMemset(p, 0, bytes));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    c->mailbox = p;
+    c->mailbox_bytes = bytes;
+    return LMCMA_HIP_OK;
+}
+
+// the exchange of the sorted costs (which = 0) or of the partial rows (which = 1), direct form
+int peer_push(lmcma_hip_ctx *c, int which)
+{
+    PeerSend s{};
     const int row = c->N + 2;
+    for (int r = 0; r < c->world; ++r) {
+        if (which == 0 && r == c->rank) continue;  // the local ranking wrote the own block in place
+        char *base = static_cast<char *>(r == c->rank ? c->mailbox : c->peer_base[r]);
+        const int d = s.n++;
+        if (which == 0) {
+            s.dst[d] = mailbox_cost(base) + (size_t)c->rank * c->nloc;
+            s.flag[d] = mailbox_flags(base) + c->rank;
+        } else {
+            s.dst[d] = mailbox_rows(base, c->lambda) + (size_t)c->rank * row;
+            s.flag[d] = r == c->rank ? nullptr : mailbox_flags(base) + kMailboxRowFlags + c->rank;
+        }
+    }
+    if (s.n == 0) return LMCMA_HIP_OK;
+    const int parts = which == 0 ? kCostParts : 1;
+    const uint32_t *src = which == 0 ? reinterpret_cast<const uint32_t *>(c->cost_all + c->first)
+                                     : reinterpret_cast<const uint32_t *>(c->partial_local);
+    const int words = which == 0 ? c->nloc : 2 * row;
+    hipLaunchKernelGGL(k_peer_push, dim3(s.n * parts), dim3(256), 0, c->stream, s, src, words, parts);
+    HIP_TRY(hipGetLastError());
+    PeerWait &w = which == 0 ? c->wait_costs : c->wait_rows;
+    w.want = c->peer_epoch * (uint32_t)parts;
+    return LMCMA_HIP_OK;
+}
+
+// One generation of a shard, in the three stretches between which the shards exchange.
+// update_due: the update of the generation before has not run yet (the gathered rows are in
+// partial_all): it runs at the head of this generation's sampling launch where that form exists,
+// as between two generations of lmcma_hip_run, else as a launch of its own first.
+int shard_stretch_local(lmcma_hip_ctx *c, bool update_due)
+{
     int rc = phase_local_checks(c);
     if (rc != LMCMA_HIP_OK) return rc;
     bool carried = false;
@@ -1692,30 +1814,179 @@ int sharded_generation(lmcma_hip_ctx *c, const RcclApi *api, bool update_due = f
         if (!carried && (rc = do_update(c, c->partial_all, c->world, true)) != LMCMA_HIP_OK) return rc;
     }
     if (!carried && (rc = local_generate(c)) != LMCMA_HIP_OK) return rc;
-    if ((rc = local_rank(c)) != LMCMA_HIP_OK) return rc;
-    // in place: this shard's block lies at its offset inside the buffer of all costs
-    RCCL_TRY(api, api->AllGather(c->cost_all + c->first, c->cost_all, (size_t)c->nloc, ncclFloat32, c->comm, c->stream));
+    return local_rank(c);
+}
+
+// leave_update: this generation's update is left to the next generation's first stretch.
+int sharded_generation(lmcma_hip_ctx *c, const RcclApi *api, bool update_due = false, bool leave_update = false)
+{
+    const int row = c->N + 2;
+    int rc = shard_stretch_local(c, update_due);
+    if (rc != LMCMA_HIP_OK) return rc;
+    if (c->peer_on) {
+        ++c->peer_epoch;
+        if ((rc = peer_push(c, 0)) != LMCMA_HIP_OK) return rc;
+    } else {
+        // in place: this shard's block lies at its offset inside the buffer of all costs
+        RCCL_TRY(api, api->AllGather(c->cost_all + c->first, c->cost_all, (size_t)c->nloc, ncclFloat32, c->comm, c->stream));
+    }
     if ((rc = lmcma_hip_phase_rank(c)) != LMCMA_HIP_OK) return rc;
-    RCCL_TRY(api, api->AllGather(c->partial_local, c->partial_all, (size_t)row, ncclFloat64, c->comm, c->stream));
+    if (c->peer_on) {
+        if ((rc = peer_push(c, 1)) != LMCMA_HIP_OK) return rc;
+    } else {
+        RCCL_TRY(api, api->AllGather(c->partial_local, c->partial_all, (size_t)row, ncclFloat64, c->comm, c->stream));
+    }
     return leave_update ? LMCMA_HIP_OK : lmcma_hip_phase_update(c, c->world);
 }
 
 }  // namespace
 
+int lmcma_hip_peer_handle(lmcma_hip_ctx *c, char handle[LMCMA_HIP_PEER_HANDLE_BYTES])
+{
+    CTX_TRY(c);
+    if (!handle) return fail(LMCMA_HIP_ERR_ARG, "null handle");
+    if (c->Q > 1) return fail(LMCMA_HIP_ERR_STATE, "peer_handle: a context with several queries is not a shard");
+    if (!c->merge_protocol)
+        return fail(LMCMA_HIP_ERR_UNSUPPORTED, "peer_handle: the direct exchange serves shards that exchange sorted lists "
+                                                "(lambda_local a multiple of 64, at most 32768, lambda_total at most 2^19)");
+    int rc = ensure_mailbox(c);
+    if (rc != LMCMA_HIP_OK) return rc;
+    PeerHandle h{};
+    h.magic = kPeerMagic;
+    h.pid = (int32_t)getpid();
+    h.device = c->cfg.device;
+    h.fine = c->mailbox_fine ? 1 : 0;
+    h.ptr = (uint64_t)(uintptr_t)c->mailbox;
+    h.bytes = c->mailbox_bytes;
+    h.lambda = c->lambda;
+    h.N = c->N;
+    // (a process that only talks to itself needs no IPC handle; a failure here surfaces when another process opens it)
+    if (hipIpcGetMemHandle(&h.ipc, c->mailbox) != hipSuccess) {
+        (void)hipGetLastError();
+        memset(&h.ipc, 0, sizeof(h.ipc));
+        h.fine |= 2;  // no IPC handle
+    }
+    memset(handle, 0, LMCMA_HIP_PEER_HANDLE_BYTES);
+    memcpy(handle, &h, sizeof(h));
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_peer_disconnect(lmcma_hip_ctx *c)
+{
+    if (!c) return fail(LMCMA_HIP_ERR_ARG, "null context");
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int r = 0; r < kMaxPeerRanks; ++r) {
+        if (c->peer_base[r] && c->peer_ipc[r]) (void)hipIpcCloseMemHandle(c->peer_base[r]);
+        c->peer_base[r] = nullptr;
+        c->peer_ipc[r] = false;
+    }
+    if (c->peer_on) {
+        drop_graph(c);
+        c->cost_all = c->arena_cost_all;
+        c->partial_all = c->arena_partial_all;
+        c->peer_on = false;
+        c->wait_costs = PeerWait{};
+        c->wait_rows = PeerWait{};
+        if (!c->comm) { c->world = 0; c->rank = 0; }
+    }
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_peer_connect(lmcma_hip_ctx *c, const char *handles, int world, int rank)
+{
+    CTX_TRY(c);
+    if (!handles) return fail(LMCMA_HIP_ERR_ARG, "null handles");
+    if (c->peer_on) return fail(LMCMA_HIP_ERR_STATE, "peer_connect: the context is connected already");
+    if (!c->mailbox) return fail(LMCMA_HIP_ERR_STATE, "peer_connect: lmcma_hip_peer_handle must come first");
+    if (world > kMaxPeerRanks) return fail(LMCMA_HIP_ERR_UNSUPPORTED, "peer_connect: at most 16 shards exchange directly");
+    int rc = check_shard(c, world, rank);
+    if (rc != LMCMA_HIP_OK) return rc;
+    if (c->comm && (c->world != world || c->rank != rank))
+        return fail(LMCMA_HIP_ERR_ARG, "peer_connect: world / rank differ from the communicator's");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < world; ++r) {
+        PeerHandle h;
+        memcpy(&h, handles + (size_t)r * LMCMA_HIP_PEER_HANDLE_BYTES, sizeof(h));
+        if (h.magic != kPeerMagic || h.lambda != c->lambda || h.N != c->N || h.bytes != c->mailbox_bytes) {
+            (void)lmcma_hip_peer_disconnect(c);
+            return fail(LMCMA_HIP_ERR_ARG, "peer_connect: handle " + std::to_string(r) + " is not the handle of a shard of this population");
+        }
+        if (r == rank) {
+            if (h.ptr != (uint64_t)(uintptr_t)c->mailbox || h.pid != (int32_t)getpid()) {
+                (void)lmcma_hip_peer_disconnect(c);
+                return fail(LMCMA_HIP_ERR_ARG, "peer_connect: handle `rank` is not this context's");
+            }
+            continue;
+        }
+        if (h.pid == (int32_t)getpid()) {
+            // a shard of this process: its pointer as it is; another device's memory needs peer access
+            if (h.device != c->cfg.device) {
+                const hipError_t e = hipDeviceEnablePeerAccess(h.device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                    (void)lmcma_hip_peer_disconnect(c);
+                    return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+                }
+                (void)hipGetLastError();
+            }
+            c->peer_base[r] = (void *)(uintptr_t)h.ptr;
+        } else {
+            if (h.fine & 2) {
+                (void)lmcma_hip_peer_disconnect(c);
+                return fail(LMCMA_HIP_ERR_RUNTIME, "peer_connect: shard " + std::to_string(r) + " could not export its mailbox (hipIpcGetMemHandle failed there)");
+            }
+            void *p = nullptr;
+            const hipError_t e = hipIpcOpenMemHandle(&p, h.ipc, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) {
+                (void)lmcma_hip_peer_disconnect(c);
+                return fail(LMCMA_HIP_ERR_RUNTIME, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+            }
+            c->peer_base[r] = p;
+            c->peer_ipc[r] = true;
+        }
+    }
+    drop_graph(c);
+    // from here on the buffers of all costs and of all rows are the mailbox's
+    c->arena_cost_all = c->cost_all;
+    c->arena_partial_all = c->partial_all;
+    c->cost_all = mailbox_cost(c->mailbox);
+    c->partial_all = mailbox_rows(c->mailbox, c->lambda);
+    uint32_t *flags = mailbox_flags(c->mailbox);
+    c->wait_costs = PeerWait{flags, 0u, world, rank, flags + kMailboxError};
+    c->wait_rows = PeerWait{flags + kMailboxRowFlags, 0u, world, rank, flags + kMailboxError};
+    c->peer_epoch = 0;
+    c->world = world;
+    c->rank = rank;
+    c->peer_on = true;
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_peer_status(lmcma_hip_ctx *c, int *fine_grained, int *wait_error)
+{
+    CTX_TRY(c);
+    if (!c->mailbox) return fail(LMCMA_HIP_ERR_STATE, "peer_status: the context has no mailbox");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, mailbox_flags(c->mailbox) + kMailboxError, sizeof(err), hipMemcpyDeviceToHost));
+    if (fine_grained) *fine_grained = c->mailbox_fine ? 1 : 0;
+    if (wait_error) *wait_error = (int)err;
+    return LMCMA_HIP_OK;
+}
+
 int lmcma_hip_run_sharded(lmcma_hip_ctx *c, int n_generations)
 {
     CTX_TRY(c);
-    if (!c->comm) return fail(LMCMA_HIP_ERR_STATE, "run_sharded: comm_init or comm_attach must come first");
+    if (!c->comm && !c->peer_on) return fail(LMCMA_HIP_ERR_STATE, "run_sharded: comm_init, comm_attach or peer_connect must come first");
     if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
     if (n_generations < 0) return fail(LMCMA_HIP_ERR_ARG, "negative generation count");
-    const RcclApi *api = rccl_api();
+    const RcclApi *api = c->peer_on ? nullptr : rccl_api();
     int left = n_generations;
     // Opt-in (LMCMA_HIP_SHARD_GRAPH=1): two generations, collectives included, recorded into one
     // HIP graph and replayed (two because the sorted-cost buffers alternate).  Queuing a generation
     // from the host takes ~17 us without it, well below a sharded generation's device time, so the
     // default is the plain loop; every rank of a population must make the same choice.
     static const bool want_graph = getenv("LMCMA_HIP_SHARD_GRAPH") != nullptr && getenv("LMCMA_HIP_NO_GRAPH") == nullptr;
-    if (want_graph && !c->timing && left > 0) {
+    if (want_graph && !c->peer_on && !c->timing && left > 0) {
         if (!c->shard_graph_exec) {
             if (!c->warmed) {
                 int rc = sharded_generation(c, api);   // module loads and LDS attribute calls stay out of the capture
@@ -1750,6 +2021,68 @@ int lmcma_hip_run_sharded(lmcma_hip_ctx *c, int n_generations)
     return LMCMA_HIP_OK;
 }
 
+int lmcma_hip_run_sharded_group(lmcma_hip_ctx **ctxs, int world, int n_generations)
+{
+    if (!ctxs || world < 1 || world > kMaxPartials) return fail(LMCMA_HIP_ERR_ARG, "run_sharded_group: 1 to 64 contexts are needed");
+    if (n_generations < 0) return fail(LMCMA_HIP_ERR_ARG, "negative generation count");
+    for (int r = 0; r < world; ++r) {
+        lmcma_hip_ctx *c = ctxs[r];
+        CTX_TRY(c);
+        int rc = check_shard(c, world, r);
+        if (rc != LMCMA_HIP_OK) return rc;
+        if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
+        if (c->lambda != ctxs[0]->lambda || c->N != ctxs[0]->N || c->nloc != ctxs[0]->nloc)
+            return fail(LMCMA_HIP_ERR_ARG, "run_sharded_group: the contexts are not shards of one population");
+        if (c->peer_on || c->comm) return fail(LMCMA_HIP_ERR_STATE, "run_sharded_group: the contexts must not be connected otherwise");
+        for (int q = 0; q < r; ++q)
+            if (ctxs[q] == c) return fail(LMCMA_HIP_ERR_ARG, "run_sharded_group: a context is named twice");
+        for (hipEvent_t &ev : c->group_ev)
+            if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const size_t nloc = ctxs[0]->nloc, row = ctxs[0]->N + 2;
+    for (int g = 0; g < n_generations; ++g) {
+        for (int r = 0; r < world; ++r) {
+            lmcma_hip_ctx *c = ctxs[r];
+            CTX_TRY(c);
+            c->world = world;  // (the update reads `world` gathered rows)
+            c->rank = r;
+            int rc = shard_stretch_local(c, g > 0);
+            if (rc != LMCMA_HIP_OK) return rc;
+            HIP_TRY(hipEventRecord(c->group_ev[0], c->stream));
+        }
+        for (int r = 0; r < world; ++r) {
+            lmcma_hip_ctx *c = ctxs[r];
+            CTX_TRY(c);
+            for (int p = 0; p < world; ++p) {
+                if (p == r) continue;
+                const lmcma_hip_ctx *o = ctxs[p];
+                HIP_TRY(hipStreamWaitEvent(c->stream, o->group_ev[0], 0));
+                HIP_TRY(hipMemcpyPeerAsync(c->cost_all + p * nloc, c->cfg.device, o->cost_all + p * nloc, o->cfg.device,
+                                           nloc * sizeof(float), c->stream));
+            }
+            int rc = lmcma_hip_phase_rank(c);
+            if (rc != LMCMA_HIP_OK) return rc;
+            HIP_TRY(hipEventRecord(c->group_ev[1], c->stream));
+        }
+        for (int r = 0; r < world; ++r) {
+            lmcma_hip_ctx *c = ctxs[r];
+            CTX_TRY(c);
+            for (int p = 0; p < world; ++p) {
+                const lmcma_hip_ctx *o = ctxs[p];
+                if (p != r) HIP_TRY(hipStreamWaitEvent(c->stream, o->group_ev[1], 0));
+                HIP_TRY(hipMemcpyPeerAsync(c->partial_all + p * row, c->cfg.device, o->partial_local, o->cfg.device,
+                                           row * sizeof(double), c->stream));
+            }
+            if (g == n_generations - 1) {
+                int rc = lmcma_hip_phase_update(c, world);
+                if (rc != LMCMA_HIP_OK) return rc;
+            }
+        }
+    }
+    for (int r = 0; r < world; ++r) { ctxs[r]->world = 0; ctxs[r]->rank = 0; }
+    return LMCMA_HIP_OK;
+}
+
 int lmcma_hip_opt_get(lmcma_hip_ctx *c, lmcma_hip_opt_summary *summary, double *xmean)
 {
     CTX_TRY(c);
@@ -1760,6 +2093,13 @@ int lmcma_hip_opt_get(lmcma_hip_ctx *c, lmcma_hip_opt_summary *summary, double *
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (o.done == 3)
         return fail(LMCMA_HIP_ERR_RUNTIME, "an update gave up waiting for the other workgroups of its launch; the state is stale");
+    if (c->peer_on) {
+        uint32_t err = 0;
+        HIP_TRY(hipMemcpy(&err, static_cast<uint32_t *>(c->mailbox) + 128, sizeof(err), hipMemcpyDeviceToHost));
+        if (err != 0)
+            return fail(LMCMA_HIP_ERR_RUNTIME, "a kernel gave up waiting for the block of shard " + std::to_string((int)err - 1) +
+                                               " (direct exchange); the state is meaningless");
+    }
     if (summary) {
         summary->itr = o.itr;
         summary->iterator_sz = o.iterator_sz;

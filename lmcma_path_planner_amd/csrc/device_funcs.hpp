@@ -17,6 +17,36 @@ __device__ __forceinline__ void shift_ptr(T *&p, size_t bytes)
 }
 
 
+// ---- direct exchange: the consumer's wait (PeerWait) ------------------------------------
+// Called by every thread of a workgroup, before its first read of what the peers send.  The first
+// wave watches one counter per lane; the wait ends when every other source has arrived or after
+// kPeerWaitTicks of the 100 MHz clock (then *error is set and the kernel goes on with whatever the
+// mailbox holds: every wave reaches its end whatever the peers do, and the host reports the error).
+constexpr unsigned long long kPeerWaitTicks = 400000000ull;  // 4 s
+
+__device__ __forceinline__ void peer_wait(const PeerWait &w)
+{
+    if (w.flags == nullptr) return;  // (uniform: a kernel argument)
+    if (threadIdx.x < 64) {
+        // (a wait that gave up before has set the error word: the run is lost, nothing waits again)
+        const bool lost = __hip_atomic_load(w.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+        if (!lost && (int)threadIdx.x < w.n && (int)threadIdx.x != w.self) {
+            const uint32_t *f = w.flags + threadIdx.x;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - w.want) < 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > kPeerWaitTicks) {
+                    __hip_atomic_store(w.error, 1u + (uint32_t)threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // what the peers stored before they bumped their counters is visible to the loads below
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
 // ---- counter-based normals ---------------------------------------------------------
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,

@@ -18,6 +18,30 @@ struct Batch {
     size_t stride;
 };
 
+// ---- direct exchange between the shards of a population ------------------------------------
+// Every shard owns a "mailbox" in fine-grained device memory that its peers can write (mapped
+// through IPC handles, or plain pointers inside one process): the buffer of all sorted costs, the
+// buffer of all partial rows, and one arrival counter per source and exchange.  A producer stores
+// its block into every peer's mailbox, makes the stores visible at system scope and adds 1 to its
+// counter there; the consuming kernel waits at its head until every other source's counter has
+// reached the value this exchange brings it to.  Counters only grow (wrap-around compare).
+constexpr int kMaxPeerRanks = 16;
+
+struct PeerWait {
+    const uint32_t *flags;  // [n] counters of this exchange in the own mailbox; null: nothing to wait for
+    uint32_t want;          // value every other source's counter reaches with this exchange
+    int n, self;            // sources; the own one is not waited for
+    uint32_t *error;        // set to a non-zero code when the wait gives up (a peer never arrived)
+};
+
+struct PeerSend {
+    // destination d of n: where this shard's block goes in that mailbox, and the counter to bump
+    // (null: the shard's own copy, which needs no counter)
+    void *dst[kMaxPeerRanks];
+    uint32_t *flag[kMaxPeerRanks];
+    int n;
+};
+
 // Scalars the sampling kernel reads from device memory, so that a captured
 // graph of one generation can be replayed without patching kernel arguments.
 struct SampleScalars {
@@ -191,6 +215,7 @@ struct MergeArgs {
     const double *weights;
     int mu;
     double *block_partials;
+    PeerWait wait;                // the lists arrive through the direct exchange (flags null: they are there)
 };
 bool rank_merge_possible(int lambda, int n_local, int first_candidate);
 // tile length for ranking a whole population in one context by tiles + merge, 0: not this way
@@ -251,6 +276,7 @@ struct UpdateArgs {
     float *xmean_f;             // [ld]
     float *V_f, *B_f;           // [m][ld] in iterator order, B = M^(k-1-t) nj pc
     Batch batch;
+    PeerWait wait;              // the partial rows arrive through the direct exchange (flags null: they are there)
 };
 hipError_t launch_update(hipStream_t s, const UpdateArgs &a);
 // The update in two launches (update_body.hpp): vectors that do not depend on this generation's

@@ -237,6 +237,36 @@ class HipContext:
     def run_sharded(self, generations):
         check_hip(self.lib.lmcma_hip_run_sharded(self._h, int(generations)), "lmcma_hip_run_sharded")
 
+    # ---- the same loop with the direct exchange (mailboxes the shards write into) -----------
+    def peer_handle(self):
+        """128 bytes that let the other shards map this context's mailbox."""
+        buf = ctypes.create_string_buffer(128)
+        check_hip(self.lib.lmcma_hip_peer_handle(self._h, buf), "lmcma_hip_peer_handle")
+        return buf.raw
+
+    def peer_connect(self, handles, rank):
+        """handles: the peer_handle() of every shard, in rank order (this context's included)."""
+        blob = b"".join(bytes(h) for h in handles)
+        if len(blob) != 128 * len(handles):
+            raise ValueError("every handle has 128 bytes")
+        check_hip(self.lib.lmcma_hip_peer_connect(self._h, blob, len(handles), int(rank)), "lmcma_hip_peer_connect")
+
+    def peer_disconnect(self):
+        check_hip(self.lib.lmcma_hip_peer_disconnect(self._h), "lmcma_hip_peer_disconnect")
+
+    def peer_status(self):
+        fine, err = ctypes.c_int(0), ctypes.c_int(0)
+        check_hip(self.lib.lmcma_hip_peer_status(self._h, ctypes.byref(fine), ctypes.byref(err)), "lmcma_hip_peer_status")
+        return dict(fine_grained=bool(fine.value), wait_error=err.value)
+
+    @staticmethod
+    def run_sharded_group(contexts, generations):
+        """The shards of one population held by this process (contexts[r] = shard r): the loop with
+        the exchanges as device copies ordered by events."""
+        arr = (ctypes.c_void_p * len(contexts))(*[c._h for c in contexts])
+        check_hip(_lib.load().lmcma_hip_run_sharded_group(arr, len(contexts), int(generations)),
+                  "lmcma_hip_run_sharded_group")
+
     def opt_get(self):
         sm = OptSummary()
         xm = np.empty(self.N, dtype=np.float64)
