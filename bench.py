@@ -7,9 +7,17 @@ grid / 64-waypoint / lambda=4096 / m=16 configuration, one process per GPU.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Started without WORLD_SIZE and with --gpus N > 1 the program launches its own N ranks
+(a child torch.distributed.run; the parent never touches a GPU) and refuses when the
+node has fewer GPUs than ranks (--oversubscribe lets ranks share GPUs: a rehearsal).
+
 A step is one generation over the whole population.  With N > 1 the population
-grows with N (4096 candidates per GPU: weak scaling) and two all-gathers per
-generation exchange the costs and the elite partial sums.  The optimiser is put
+grows with N (4096 candidates per GPU: weak scaling) and the shards exchange twice per
+generation: their sorted costs and one row of N + 2 doubles each (elite partial sum,
+success-rule count, lowest cost) -- directly into each other's mailboxes over xGMI
+(--exchange peer, the default; checked against the RCCL form bit for bit before the
+timed region, which falls back to RCCL if the check fails) or by two RCCL all-gathers
+(--exchange library); the other form is timed as well and reported beside the headline.  The optimiser is put
 back to its initial state every EPISODE generations (a new planning query on the
 same map), so that every timed generation works on a live search distribution
 instead of one that has already collapsed (sigma < 1e-20 is the reference's stop
@@ -176,14 +184,33 @@ def main():
     ap.add_argument("--sharded-loop", action="store_true",
                     help="N = 1 only: go through lmcma_hip_run_sharded with a one-rank RCCL communicator, i.e. "
                     "what every rank of an N > 1 job runs (not the headline: the graph-replayed lmcma_hip_run is)")
-    ap.add_argument("--exchange", default="library", choices=["library", "torch"],
-                    help="N > 1: 'library' = the sharded loop inside the library (lmcma_hip_run_sharded: RCCL "
-                    "all-gathers queued by the library between its phases, no host code per generation); 'torch' = "
-                    "the same loop driven from Python with torch.distributed all-gathers (the only choice with "
-                    "--backend gloo)")
+    ap.add_argument("--exchange", default="peer", choices=["peer", "library", "torch"],
+                    help="N > 1: 'peer' = the sharded loop inside the library with the direct exchange (every shard "
+                    "stores its blocks into the peers' mailboxes, the consuming kernels wait for arrival counters); "
+                    "'library' = the same loop with two RCCL all-gathers per generation; 'torch' = the loop driven "
+                    "from Python with torch.distributed all-gathers (a rehearsal form)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="let the ranks share the GPUs when the node has fewer than --gpus (a rehearsal of the N > 1 "
+                    "path, not a measurement: backend gloo, the direct exchange over IPC on one device)")
     args = ap.parse_args()
 
     import torch
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # This process starts the ranks and never touches a GPU itself (counting devices does not).
+        have = torch.cuda.device_count()
+        if have < args.gpus and not args.oversubscribe:
+            raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s); refusing to run fewer ranks than asked "
+                             "for (--oversubscribe rehearses the path with ranks sharing GPUs)" % (args.gpus, have))
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     import torch.distributed as dist
     from lmcma_path_planner_amd import grids, hip
     from lmcma_path_planner_amd import dist as shard_mod
@@ -191,10 +218,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if world > torch.cuda.device_count():
+        if not args.oversubscribe:
+            raise SystemExit("%d ranks on %d GPU(s): --oversubscribe is needed for that" % (world, torch.cuda.device_count()))
+        args.backend = "gloo"       # RCCL refuses two ranks on one device
+        if args.exchange == "library":
+            raise SystemExit("--oversubscribe: the RCCL exchange cannot run with ranks sharing a GPU")
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -208,7 +241,10 @@ def main():
     prob = grids.benchmark_problem(args.config)
     lam_local = prob.lam if args.config <= 3 else prob.lam // 8   # cfg4/5 are quoted as 8-GPU populations
     lam_total = lam_local * world
-    native = world > 1 and args.backend == "nccl" and args.exchange == "library"
+    native = world > 1 and args.exchange in ("peer", "library")
+    have_rccl = world > 1 and args.backend == "nccl"
+    if world > 1 and args.exchange == "library" and not have_rccl:
+        raise SystemExit("--exchange library needs --backend nccl")
     stream = None
     if world > 1 and not native:
         # kernels and collectives are ordered on one non-default torch stream
@@ -230,6 +266,7 @@ def main():
     # the calls of run_steps: warm-up and timed region are stretches of the same sequence of
     # episodes, and a reset falls where an episode ends, not where a region starts.
     episode = [0]
+    exchange_used, exchange_check = ("torch" if world > 1 else "none"), None
     if world == 1 and args.sharded_loop:
         with stdout_to_stderr():
             ctx.comm_init(hip.HipContext.comm_unique_id(), 1, 0)
@@ -254,11 +291,46 @@ def main():
                 done += n
                 episode[0] = (episode[0] + n) % EPISODE
     elif native:
-        # one RCCL communicator of the library's own: rank 0 makes the id, torch.distributed carries it
         with stdout_to_stderr():
-            uid = [hip.HipContext.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            ctx.comm_init(uid[0], world, rank)
+            if have_rccl:
+                # one RCCL communicator of the library's own: rank 0 makes the id, torch.distributed carries it
+                uid = [hip.HipContext.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                ctx.comm_init(uid[0], world, rank)
+            if args.exchange == "peer":
+                # the mailboxes: every shard's handle to every shard, all mapped before anyone sends
+                handles = [None] * world
+                dist.all_gather_object(handles, ctx.peer_handle())
+                ctx.peer_connect(handles, rank)
+                dist.barrier()
+                exchange_used = "peer"
+                if have_rccl:
+                    # the direct exchange against the RCCL form on this very node: same bits, or RCCL it is
+                    def probe():
+                        ctx.opt_reset()
+                        ctx.run_sharded(6)
+                        ctx.synchronize()
+                        try:
+                            st_ = ctx.opt_get()
+                        except Exception:
+                            return None
+                        return np.concatenate([st_["xmean"], [st_["sigma"], st_["s"], st_["best_f"]]]).tobytes()
+                    a_ = probe()
+                    ctx.peer_enable(False)
+                    b_ = probe()
+                    okf = torch.tensor([1 if (a_ is not None and a_ == b_) else 0], device=device)
+                    dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+                    exchange_check = "identical to the RCCL form over 6 generations" if int(okf.item()) == 1 else \
+                        "DIFFERS from the RCCL form or timed out: the RCCL form is what was timed"
+                    if int(okf.item()) == 1:
+                        ctx.peer_enable(True)
+                    else:
+                        exchange_used = "library"
+                    ctx.opt_reset()
+                else:
+                    exchange_check = "not checked (no RCCL with ranks sharing a GPU)"
+            else:
+                exchange_used, exchange_check = "library", None
 
         def run_steps(k):
             done = 0
@@ -310,8 +382,9 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     device_ms = ctx.stream_elapsed()        # HIP events on the library's stream around the same K steps
+    rdev = device if args.backend == "nccl" else torch.device("cpu")   # where the ranks' scalars are reduced
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -384,9 +457,14 @@ def main():
                        "lambda_total": lam_total, "m": prob.m, "queries_in_flight": args.queries,
                        "z_source": "philox4x32-10",
                        "update": "on device, fp64", "episode_generations": EPISODE,
-                       "exchange": ("all-gather of sorted local costs + all-gather of elite partial sums (N+2 doubles "
-                                    "per rank), " + ("RCCL calls inside the library" if native else
-                                                     "torch.distributed calls from Python")) if world > 1 else "none"},
+                       "exchange": ("sorted local costs + one row of N+2 doubles per shard (elite partial sum, "
+                                    "success-rule count, lowest cost), " +
+                                    {"peer": "stored by each shard into the peers' mailboxes (fine-grained memory mapped "
+                                             "over IPC, arrival counters, the consuming kernels wait at their head)",
+                                     "library": "two RCCL all-gathers queued by the library",
+                                     "torch": "torch.distributed all-gathers from Python"}[exchange_used])
+                       if world > 1 else "none",
+                       "exchange_check": exchange_check},
             "roofline": {"bound": "hbm", "kernel": "one generation: " + " + ".join(k for k in per_kernel),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
@@ -404,7 +482,32 @@ def main():
             cores = host_threads()
             out["cpu_baseline"] = cpu_baseline(prob, cores, 12.0)
             out["cpu_baseline_1thread"] = cpu_baseline(prob, 1, 8.0)
+    alt = None
+    if world > 1 and native and have_rccl and args.exchange == "peer":
+        # the other exchange form on the same contexts, timed the same way (a shorter region)
+        other_is_peer = exchange_used != "peer"
+        if not other_is_peer or exchange_check is None or "identical" in exchange_check:
+            ctx.peer_enable(other_is_peer)
+            k_alt = min(args.steps, 400)
+            run_steps(100)
+            fence()
+            t0 = time.perf_counter()
+            run_steps(k_alt)
+            fence()
+            el = time.perf_counter() - t0
+            t = torch.tensor([el], dtype=torch.float64, device=rdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            alt = {"exchange": "peer" if other_is_peer else "library (two RCCL all-gathers)",
+                   "value": lam_total * k_alt / float(t.item()), "unit": "candidate-trajectories/s", "steps": k_alt,
+                   "ms_per_step": float(t.item()) / k_alt * 1e3}
+    if rank == 0:
+        if alt is not None:
+            out["exchange_alternative"] = alt
+        if world > 1 and args.exchange == "peer":
+            out["peer_status"] = ctx.peer_status()
         print(json.dumps(out))
+    if world > 1:
+        dist.barrier()      # nobody unmaps a mailbox a peer may still write into
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

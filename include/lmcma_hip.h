@@ -307,6 +307,9 @@ int lmcma_hip_run_sharded(lmcma_hip_ctx *ctx, int n_generations);
  *                            directly (a communicator the context may also have is not used).
  *                            world <= 16.  Every shard must connect before any shard runs, and
  *                            all shards make the same run_sharded calls.
+ * lmcma_hip_peer_enable      on = 0: run_sharded goes back to the communicator while the mailboxes stay
+ *                            mapped; on = 1: the direct exchange again.  Every shard makes the same
+ *                            switch between the same two run_sharded calls.
  * lmcma_hip_peer_disconnect  unmaps; run_sharded is back to the communicator
  * lmcma_hip_peer_status      after the context's work has finished: whether the mailbox is
  *                            fine-grained memory, and whether a wait for a peer gave up (non-zero:
@@ -319,6 +322,7 @@ int lmcma_hip_run_sharded(lmcma_hip_ctx *ctx, int n_generations);
 #define LMCMA_HIP_PEER_HANDLE_BYTES 128
 int lmcma_hip_peer_handle(lmcma_hip_ctx *ctx, char handle[LMCMA_HIP_PEER_HANDLE_BYTES]);
 int lmcma_hip_peer_connect(lmcma_hip_ctx *ctx, const char *handles, int world, int rank);
+int lmcma_hip_peer_enable(lmcma_hip_ctx *ctx, int on);
 int lmcma_hip_peer_disconnect(lmcma_hip_ctx *ctx);
 int lmcma_hip_peer_status(lmcma_hip_ctx *ctx, int *fine_grained, int *wait_error);
 int lmcma_hip_run_sharded_group(lmcma_hip_ctx **ctxs, int world, int n_generations);

@@ -162,6 +162,7 @@ SIGNATURES = {
     "lmcma_hip_run_sharded": (_i, [_vp, _i]),
     "lmcma_hip_peer_handle": (_i, [_vp, ctypes.c_char_p]),
     "lmcma_hip_peer_connect": (_i, [_vp, ctypes.c_char_p, _i, _i]),
+    "lmcma_hip_peer_enable": (_i, [_vp, _i]),
     "lmcma_hip_peer_disconnect": (_i, [_vp]),
     "lmcma_hip_peer_status": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "lmcma_hip_run_sharded_group": (_i, [ctypes.POINTER(_vp), _i, _i]),

@@ -203,7 +203,10 @@ struct lmcma_hip_ctx {
     // memory the peers write into) and the peers' mailboxes as mapped here
     void *mailbox = nullptr;
     size_t mailbox_bytes = 0;
-    bool mailbox_fine = false, peer_on = false;
+    bool mailbox_fine = false;
+    bool peer_mapped = false;              // the peers' mailboxes are mapped (lmcma_hip_peer_connect)
+    bool peer_on = false;                  // ... and lmcma_hip_run_sharded exchanges through them
+    bool peer_wait_kernels = false;        // see lmcma_hip_peer_connect
     void *peer_base[kMaxPeerRanks] = {};
     bool peer_ipc[kMaxPeerRanks] = {};     // mapped with hipIpcOpenMemHandle (to be closed)
     uint32_t peer_epoch = 0;               // exchanges of each kind made so far (every shard counts alike)
@@ -455,7 +458,7 @@ UpdateArgs update_args(const lmcma_hip_ctx *c, const double *partials, int n_par
     a.t = c->t; a.vec = c->vec; a.iterator = c->iterator;
     a.xmean_f = c->xmean_f; a.V_f = c->V_f; a.B_f = c->B_f;
     a.batch = batch_of(c);
-    if (rows_with_scalars && c->peer_on && partials == c->partial_all) a.wait = c->wait_rows;
+    if (rows_with_scalars && c->peer_on && !c->peer_wait_kernels && partials == c->partial_all) a.wait = c->wait_rows;
     return a;
 }
 
@@ -1513,7 +1516,7 @@ int lmcma_hip_phase_rank(lmcma_hip_ctx *c)
             a.rows = c->rows; a.ld = c->ld; a.N = c->N;
             a.weights = c->weights; a.mu = c->mu;
             a.block_partials = c->block_partials;
-            if (c->peer_on) a.wait = c->wait_costs;
+            if (c->peer_on && !c->peer_wait_kernels) a.wait = c->wait_costs;
             HIP_TRY(launch_rank_merge(c->stream, a, &rows));
             c->psr_parts_n = rows;
             c->ranked_local_only = true;
@@ -1689,7 +1692,7 @@ int lmcma_hip_comm_destroy(lmcma_hip_ctx *c)
     if (c->comm) drop_graph(c);   // a recorded sharded generation holds this communicator's collectives
     c->comm = nullptr;
     c->own_comm = false;
-    if (!c->peer_on) {
+    if (!c->peer_mapped) {
         c->world = 0;
         c->rank = 0;
     }
@@ -1725,6 +1728,10 @@ __global__ __launch_bounds__(256) void k_peer_push(const PeerSend s, const uint3
         __hip_atomic_fetch_add(s.flag[d], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The consumer's wait as a launch of its own (one wave): for shards that share a GPU, where
+// consumers that wait in all their workgroups would keep the peers' kernels off the device.
+__global__ __launch_bounds__(64) void k_peer_wait(const PeerWait w) { peer_wait(w); }
+
 // layout of a mailbox (the same in every shard of a population: it depends on lambda and N only)
 constexpr size_t kMailboxFlagBytes = 1024;   // [0, 64) cost counters, [64, 128) row counters, [128] error word
 constexpr int kMailboxRowFlags = 64, kMailboxError = 128;
@@ -1739,6 +1746,7 @@ struct PeerHandle {
     int32_t pid, device, fine;
     uint64_t ptr, bytes;
     int32_t lambda, N;
+    char bus[16];   // PCI bus id of the shard's GPU: shards with the same one share a device
     hipIpcMemHandle_t ipc;
 };
 static_assert(sizeof(PeerHandle) <= LMCMA_HIP_PEER_HANDLE_BYTES, "the handle blob holds a PeerHandle");
@@ -1796,6 +1804,10 @@ int peer_push(lmcma_hip_ctx *c, int which)
     HIP_TRY(hipGetLastError());
     PeerWait &w = which == 0 ? c->wait_costs : c->wait_rows;
     w.want = c->peer_epoch * (uint32_t)parts;
+    if (c->peer_wait_kernels) {
+        hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, c->stream, w);
+        HIP_TRY(hipGetLastError());
+    }
     return LMCMA_HIP_OK;
 }
 
@@ -1860,6 +1872,11 @@ int lmcma_hip_peer_handle(lmcma_hip_ctx *c, char handle[LMCMA_HIP_PEER_HANDLE_BY
     h.bytes = c->mailbox_bytes;
     h.lambda = c->lambda;
     h.N = c->N;
+    {
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), c->cfg.device) != hipSuccess) (void)hipGetLastError();
+        strncpy(h.bus, bus, sizeof(h.bus) - 1);
+    }
     // (a process that only talks to itself needs no IPC handle; a failure here surfaces when another process opens it)
     if (hipIpcGetMemHandle(&h.ipc, c->mailbox) != hipSuccess) {
         (void)hipGetLastError();
@@ -1881,11 +1898,14 @@ int lmcma_hip_peer_disconnect(lmcma_hip_ctx *c)
         c->peer_base[r] = nullptr;
         c->peer_ipc[r] = false;
     }
-    if (c->peer_on) {
+    if (c->peer_mapped) {
         drop_graph(c);
-        c->cost_all = c->arena_cost_all;
-        c->partial_all = c->arena_partial_all;
+        if (c->peer_on) {
+            c->cost_all = c->arena_cost_all;
+            c->partial_all = c->arena_partial_all;
+        }
         c->peer_on = false;
+        c->peer_mapped = false;
         c->wait_costs = PeerWait{};
         c->wait_rows = PeerWait{};
         if (!c->comm) { c->world = 0; c->rank = 0; }
@@ -1897,7 +1917,7 @@ int lmcma_hip_peer_connect(lmcma_hip_ctx *c, const char *handles, int world, int
 {
     CTX_TRY(c);
     if (!handles) return fail(LMCMA_HIP_ERR_ARG, "null handles");
-    if (c->peer_on) return fail(LMCMA_HIP_ERR_STATE, "peer_connect: the context is connected already");
+    if (c->peer_mapped) return fail(LMCMA_HIP_ERR_STATE, "peer_connect: the context is connected already");
     if (!c->mailbox) return fail(LMCMA_HIP_ERR_STATE, "peer_connect: lmcma_hip_peer_handle must come first");
     if (world > kMaxPeerRanks) return fail(LMCMA_HIP_ERR_UNSUPPORTED, "peer_connect: at most 16 shards exchange directly");
     int rc = check_shard(c, world, rank);
@@ -1905,9 +1925,13 @@ int lmcma_hip_peer_connect(lmcma_hip_ctx *c, const char *handles, int world, int
     if (c->comm && (c->world != world || c->rank != rank))
         return fail(LMCMA_HIP_ERR_ARG, "peer_connect: world / rank differ from the communicator's");
     HIP_TRY(hipStreamSynchronize(c->stream));
+    PeerHandle own;
+    memcpy(&own, handles + (size_t)rank * LMCMA_HIP_PEER_HANDLE_BYTES, sizeof(own));
+    int on_my_gpu = 0;
     for (int r = 0; r < world; ++r) {
         PeerHandle h;
         memcpy(&h, handles + (size_t)r * LMCMA_HIP_PEER_HANDLE_BYTES, sizeof(h));
+        if (h.magic == kPeerMagic && strncmp(h.bus, own.bus, sizeof(h.bus)) == 0) ++on_my_gpu;
         if (h.magic != kPeerMagic || h.lambda != c->lambda || h.N != c->N || h.bytes != c->mailbox_bytes) {
             (void)lmcma_hip_peer_disconnect(c);
             return fail(LMCMA_HIP_ERR_ARG, "peer_connect: handle " + std::to_string(r) + " is not the handle of a shard of this population");
@@ -1954,10 +1978,36 @@ int lmcma_hip_peer_connect(lmcma_hip_ctx *c, const char *handles, int world, int
     uint32_t *flags = mailbox_flags(c->mailbox);
     c->wait_costs = PeerWait{flags, 0u, world, rank, flags + kMailboxError};
     c->wait_rows = PeerWait{flags + kMailboxRowFlags, 0u, world, rank, flags + kMailboxError};
-    c->peer_epoch = 0;
+    // (peer_epoch is not reset: the counters in the mailboxes only grow, and every shard has made
+    // the same number of exchanges)
     c->world = world;
     c->rank = rank;
     c->peer_on = true;
+    c->peer_mapped = true;
+    // Shards that share a GPU (a rehearsal): a kernel that waits for a peer holds its share of the
+    // device while the peer's kernels need room to run, and consumers that wait in every workgroup
+    // (the merge, the sampling launch that carries the update) can fill the device between them.
+    // Beyond small shards the waits then become one-wave launches of their own ahead of the
+    // consumers.  One shard per GPU: the consumers wait themselves, one launch boundary fewer.
+    c->peer_wait_kernels = on_my_gpu > 1 && (long)c->nloc * on_my_gpu > 2048;
+    return LMCMA_HIP_OK;
+}
+
+int lmcma_hip_peer_enable(lmcma_hip_ctx *c, int on)
+{
+    CTX_TRY(c);
+    if (!c->peer_mapped) return fail(LMCMA_HIP_ERR_STATE, "peer_enable: lmcma_hip_peer_connect must come first");
+    if ((on != 0) == c->peer_on) return LMCMA_HIP_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);
+    if (on) {
+        c->cost_all = mailbox_cost(c->mailbox);
+        c->partial_all = mailbox_rows(c->mailbox, c->lambda);
+    } else {
+        c->cost_all = c->arena_cost_all;
+        c->partial_all = c->arena_partial_all;
+    }
+    c->peer_on = on != 0;
     return LMCMA_HIP_OK;
 }
 
@@ -1966,10 +2016,13 @@ int lmcma_hip_peer_status(lmcma_hip_ctx *c, int *fine_grained, int *wait_error)
     CTX_TRY(c);
     if (!c->mailbox) return fail(LMCMA_HIP_ERR_STATE, "peer_status: the context has no mailbox");
     HIP_TRY(hipStreamSynchronize(c->stream));
-    uint32_t err = 0;
-    HIP_TRY(hipMemcpy(&err, mailbox_flags(c->mailbox) + kMailboxError, sizeof(err), hipMemcpyDeviceToHost));
+    uint32_t err[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(err, mailbox_flags(c->mailbox) + kMailboxError, sizeof(err), hipMemcpyDeviceToHost));
     if (fine_grained) *fine_grained = c->mailbox_fine ? 1 : 0;
-    if (wait_error) *wait_error = (int)err;
+    if (wait_error) *wait_error = (int)err[0];
+    if (err[0] != 0)
+        g_last_error = "wait gave up: counter " + std::to_string(err[3]) + " held " + std::to_string(err[1]) + ", wanted " +
+                       std::to_string(err[2]) + " (exchange " + std::to_string(c->peer_epoch) + " of this shard)";
     return LMCMA_HIP_OK;
 }
 
@@ -2033,7 +2086,7 @@ int lmcma_hip_run_sharded_group(lmcma_hip_ctx **ctxs, int world, int n_generatio
         if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
         if (c->lambda != ctxs[0]->lambda || c->N != ctxs[0]->N || c->nloc != ctxs[0]->nloc)
             return fail(LMCMA_HIP_ERR_ARG, "run_sharded_group: the contexts are not shards of one population");
-        if (c->peer_on || c->comm) return fail(LMCMA_HIP_ERR_STATE, "run_sharded_group: the contexts must not be connected otherwise");
+        if (c->peer_mapped || c->comm) return fail(LMCMA_HIP_ERR_STATE, "run_sharded_group: the contexts must not be connected otherwise");
         for (int q = 0; q < r; ++q)
             if (ctxs[q] == c) return fail(LMCMA_HIP_ERR_ARG, "run_sharded_group: a context is named twice");
         for (hipEvent_t &ev : c->group_ev)
@@ -2093,7 +2146,7 @@ int lmcma_hip_opt_get(lmcma_hip_ctx *c, lmcma_hip_opt_summary *summary, double *
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (o.done == 3)
         return fail(LMCMA_HIP_ERR_RUNTIME, "an update gave up waiting for the other workgroups of its launch; the state is stale");
-    if (c->peer_on) {
+    if (c->mailbox) {
         uint32_t err = 0;
         HIP_TRY(hipMemcpy(&err, static_cast<uint32_t *>(c->mailbox) + 128, sizeof(err), hipMemcpyDeviceToHost));
         if (err != 0)

@@ -36,6 +36,10 @@ __device__ __forceinline__ void peer_wait(const PeerWait &w)
             while ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - w.want) < 0) {
                 __builtin_amdgcn_s_sleep(2);
                 if (__builtin_amdgcn_s_memrealtime() - t0 > kPeerWaitTicks) {
+                    // what was waited for, for the report: the counter's value, the value wanted, the counter's index
+                    w.error[1] = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    w.error[2] = w.want;
+                    w.error[3] = (uint32_t)(f - (w.error - 128));
                     __hip_atomic_store(w.error, 1u + (uint32_t)threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }

@@ -31,7 +31,9 @@ struct PeerWait {
     const uint32_t *flags;  // [n] counters of this exchange in the own mailbox; null: nothing to wait for
     uint32_t want;          // value every other source's counter reaches with this exchange
     int n, self;            // sources; the own one is not waited for
-    uint32_t *error;        // set to a non-zero code when the wait gives up (a peer never arrived)
+    // word 128 of the mailbox: set to 1 + the source when a wait gives up (a peer never arrived); the
+    // three words after it then hold the counter's value, the value wanted and the counter's index
+    uint32_t *error;
 };
 
 struct PeerSend {

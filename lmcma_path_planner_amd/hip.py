@@ -251,13 +251,20 @@ class HipContext:
             raise ValueError("every handle has 128 bytes")
         check_hip(self.lib.lmcma_hip_peer_connect(self._h, blob, len(handles), int(rank)), "lmcma_hip_peer_connect")
 
+    def peer_enable(self, on=True):
+        """False: run_sharded uses the communicator while the mailboxes stay mapped; True: back."""
+        check_hip(self.lib.lmcma_hip_peer_enable(self._h, 1 if on else 0), "lmcma_hip_peer_enable")
+
     def peer_disconnect(self):
         check_hip(self.lib.lmcma_hip_peer_disconnect(self._h), "lmcma_hip_peer_disconnect")
 
     def peer_status(self):
         fine, err = ctypes.c_int(0), ctypes.c_int(0)
         check_hip(self.lib.lmcma_hip_peer_status(self._h, ctypes.byref(fine), ctypes.byref(err)), "lmcma_hip_peer_status")
-        return dict(fine_grained=bool(fine.value), wait_error=err.value)
+        out = dict(fine_grained=bool(fine.value), wait_error=err.value)
+        if err.value:
+            out["detail"] = self.lib.lmcma_hip_last_error().decode()
+        return out
 
     @staticmethod
     def run_sharded_group(contexts, generations):

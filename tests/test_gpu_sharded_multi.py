@@ -195,3 +195,26 @@ def test_peer_errors():
         a.run_sharded(1)                                    # neither communicator nor peers
     a.close()
     b.close()
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """bench.py --gpus N without a launcher around it: it starts N ranks itself (here sharing the one
+    GPU: --oversubscribe) and rank 0 prints the one JSON line with n_gpus = N; without the switch it
+    refuses to measure fewer GPUs than it was asked for."""
+    import json
+    import torch
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--steps", "30",
+                          "--warmup", "5", "--no-cpu-baseline"], capture_output=True, text=True, timeout=280, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["lambda_total"] == 8192
+    assert rec["peer_status"]["wait_error"] == 0 and rec["value"] > 0
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5"],
+                             capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+        assert out.returncode != 0 and "refusing" in (out.stdout + out.stderr)

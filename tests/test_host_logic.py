@@ -236,3 +236,19 @@ def test_user_subclass_of_cmabase_runs_like_the_reference_base_class(oracle):
         m = re.search(r"evaluations (\d+) best ([0-9.e+-]+)", out.stdout)
         assert int(m.group(1)) == 598 * 9          # sigma 0.8 * 0.97^g < 1e-8 after 598 generations
         assert float(m.group(2)) < 1e-12
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """bench.py --gpus N > 1 started bare must start N ranks or fail loudly, never run one GPU and
+    report it as N (no GPU is touched before the refusal, so this runs anywhere)."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    n = torch.cuda.device_count() + 2
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "5"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode != 0 and "refusing" in (out.stdout + out.stderr)
