@@ -306,7 +306,10 @@ int lmcma_hip_run_sharded(lmcma_hip_ctx *ctx, int n_generations);
  *                            peers' mailboxes.  From then on lmcma_hip_run_sharded exchanges
  *                            directly (a communicator the context may also have is not used).
  *                            world <= 16.  Every shard must connect before any shard runs, and
- *                            all shards make the same run_sharded calls.
+ *                            all shards make the same run_sharded calls.  A shard's own handle in
+ *                            another shard's place makes that shard an image of this one (its
+ *                            blocks land in that place too): one shard timed with the traffic
+ *                            and the waits of `world` shards; the optimisation is then not one.
  * lmcma_hip_peer_enable      on = 0: run_sharded goes back to the communicator while the mailboxes stay
  *                            mapped; on = 1: the direct exchange again.  Every shard makes the same
  *                            switch between the same two run_sharded calls.

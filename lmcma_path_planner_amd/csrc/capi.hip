@@ -206,12 +206,13 @@ struct lmcma_hip_ctx {
     bool mailbox_fine = false;
     bool peer_mapped = false;              // the peers' mailboxes are mapped (lmcma_hip_peer_connect)
     bool peer_on = false;                  // ... and lmcma_hip_run_sharded exchanges through them
-    bool peer_wait_kernels = false;        // see lmcma_hip_peer_connect
+    bool peer_image = false;               // the peers are images of this shard (its own handle in their places)
     void *peer_base[kMaxPeerRanks] = {};
     bool peer_ipc[kMaxPeerRanks] = {};     // mapped with hipIpcOpenMemHandle (to be closed)
     uint32_t peer_epoch = 0;               // exchanges of each kind made so far (every shard counts alike)
-    float *arena_cost_all = nullptr;       // the arena's own buffers, current again after peer_disconnect
-    double *arena_partial_all = nullptr;
+    uint32_t sent_costs = 0, sent_rows = 0; // counter increments per source so far (what the next wait wants)
+    bool peer_sending = false;             // inside a generation of the direct form: the producers send
+    int peer_arrivals = 0;                 // increments per destination the last producer made
     PeerWait wait_costs{}, wait_rows{};
     hipEvent_t group_ev[2] = {nullptr, nullptr};   // lmcma_hip_run_sharded_group: this shard's two hand-over points
 
@@ -398,6 +399,7 @@ int do_evaluate(lmcma_hip_ctx *c)
 }
 
 UpdateArgs update_args(const lmcma_hip_ctx *c, const double *partials, int n_partials, bool rows_with_scalars);
+PeerSend peer_send_table_if_sending(const lmcma_hip_ctx *c, int which);  // n = 0 outside the direct exchange
 
 // sample + score in one launch (device Philox stream only).
 // post: the previous generation's update, not yet applied, is to run at the head of this launch
@@ -458,7 +460,6 @@ UpdateArgs update_args(const lmcma_hip_ctx *c, const double *partials, int n_par
     a.t = c->t; a.vec = c->vec; a.iterator = c->iterator;
     a.xmean_f = c->xmean_f; a.V_f = c->V_f; a.B_f = c->B_f;
     a.batch = batch_of(c);
-    if (rows_with_scalars && c->peer_on && !c->peer_wait_kernels && partials == c->partial_all) a.wait = c->wait_rows;
     return a;
 }
 
@@ -576,8 +577,11 @@ int do_recombine_final(lmcma_hip_ctx *c, int rows, bool with_scalars)
     // one that feeds its own update must use the update's, so that reducing first and updating
     // from the one row gives the same bits as updating from the block rows.
     const int threads = c->merge_protocol ? 0 : update_threads(c->N, std::min(c->m, LMCMA_HIP_MAX_VECTORS));
+    if (with_scalars) x.send = peer_send_table_if_sending(c, 1);
+    int arrivals = 0;
     HIP_TRY(launch_recombine_final(c->stream, src, rows, c->N, c->partial_local, threads,
-                                   with_scalars ? &x : nullptr));
+                                   with_scalars ? &x : nullptr, &arrivals));
+    if (x.send.n > 0) c->peer_arrivals = arrivals;
     return LMCMA_HIP_OK;
 }
 
@@ -1516,7 +1520,6 @@ int lmcma_hip_phase_rank(lmcma_hip_ctx *c)
             a.rows = c->rows; a.ld = c->ld; a.N = c->N;
             a.weights = c->weights; a.mu = c->mu;
             a.block_partials = c->block_partials;
-            if (c->peer_on && !c->peer_wait_kernels) a.wait = c->wait_costs;
             HIP_TRY(launch_rank_merge(c->stream, a, &rows));
             c->psr_parts_n = rows;
             c->ranked_local_only = true;
@@ -1703,39 +1706,40 @@ int lmcma_hip_comm_destroy(lmcma_hip_ctx *c)
 
 namespace {
 
-// A shard's block (its sorted costs, or its row of N + 2 doubles) into every mailbox of `s`.
-// Workgroup d * parts + part copies part `part` of the block to destination d, makes its stores
-// visible at system scope, and adds 1 to that destination's arrival counter: `parts` arrivals per
-// source and exchange.
-__global__ __launch_bounds__(256) void k_peer_push(const PeerSend s, const uint32_t *__restrict__ src, int words, int parts)
+// The exchange of the sorted costs in one launch.  Send: the shard's list (`quads` 16-byte units at
+// src) into every mailbox of `s`, one unit per thread across the grid, as write-through stores; every
+// workgroup then bumps every destination's counter (gridDim.x arrivals per source and exchange).
+// Receive: wait for the peers' counters, then copy their lists (all of the mailbox's cost buffer but
+// the units [skip0, skip1) of the shard's own list) into the context's buffer of all costs.
+__global__ __launch_bounds__(256) void k_peer_exchange(const PeerSend s, const ulonglong2 *__restrict__ src, int quads,
+                                                       const PeerWait w, const uint4 *__restrict__ box, uint4 *__restrict__ all,
+                                                       int all_quads, int skip0, int skip1)
 {
-    const int tid = threadIdx.x;
-    const int d = (int)blockIdx.x / parts, part = (int)blockIdx.x - d * parts;
-    const int per = (((words + parts - 1) / parts) + 3) & ~3;  // words per part, whole 16-byte units
-    const int w0 = part * per, w1 = min(words, w0 + per);
-    uint32_t *dst = static_cast<uint32_t *>(s.dst[d]);
-    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
-        const int quads = w1 > w0 ? (w1 - w0) >> 2 : 0;
-        for (int q = tid; q < quads; q += 256)
-            reinterpret_cast<uint4 *>(dst + w0)[q] = reinterpret_cast<const uint4 *>(src + w0)[q];
-        for (int w = w0 + 4 * quads + tid; w < w1; w += 256) dst[w] = src[w];
-    } else {
-        for (int w = w0 + tid; w < w1; w += 256) dst[w] = src[w];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < s.n * quads; i += gridDim.x * 256) {
+        const int d = i / quads, q = i - d * quads;
+        const ulonglong2 v = src[q];
+        unsigned long long *dst = static_cast<unsigned long long *>(s.dst[d]) + 2 * (size_t)q;
+        peer_store(dst, v.x);
+        peer_store(dst + 1, v.y);
     }
-    __threadfence_system();
-    __syncthreads();
-    if (tid == 0 && s.flag[d] != nullptr)
-        __hip_atomic_fetch_add(s.flag[d], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    peer_arrive(s);
+    peer_wait(w);
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < all_quads; q += gridDim.x * 256)
+        if (q < skip0 || q >= skip1) all[q] = box[q];
 }
 
-// The consumer's wait as a launch of its own (one wave): for shards that share a GPU, where
-// consumers that wait in all their workgroups would keep the peers' kernels off the device.
-__global__ __launch_bounds__(64) void k_peer_wait(const PeerWait w) { peer_wait(w); }
+// The receiving side of the exchange of the rows: every workgroup waits for the peers' arrival
+// counters, then the launch copies the rows from the mailbox into the context's own buffer.
+__global__ __launch_bounds__(256) void k_peer_gather(const PeerWait w, const uint4 *__restrict__ src, uint4 *__restrict__ dst,
+                                                     int quads)
+{
+    peer_wait(w);
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < quads; q += gridDim.x * 256) dst[q] = src[q];
+}
 
 // layout of a mailbox (the same in every shard of a population: it depends on lambda and N only)
 constexpr size_t kMailboxFlagBytes = 1024;   // [0, 64) cost counters, [64, 128) row counters, [128] error word
 constexpr int kMailboxRowFlags = 64, kMailboxError = 128;
-constexpr int kCostParts = 4;                // workgroups (arrivals) per destination of the cost exchange
 
 size_t mailbox_cost_offset() { return kMailboxFlagBytes; }
 size_t mailbox_rows_offset(int lambda) { return kMailboxFlagBytes + (((size_t)lambda * sizeof(float) + 16 + 255) & ~(size_t)255); }
@@ -1746,7 +1750,6 @@ struct PeerHandle {
     int32_t pid, device, fine;
     uint64_t ptr, bytes;
     int32_t lambda, N;
-    char bus[16];   // PCI bus id of the shard's GPU: shards with the same one share a device
     hipIpcMemHandle_t ipc;
 };
 static_assert(sizeof(PeerHandle) <= LMCMA_HIP_PEER_HANDLE_BYTES, "the handle blob holds a PeerHandle");
@@ -1778,36 +1781,61 @@ int ensure_mailbox(lmcma_hip_ctx *c)
     return LMCMA_HIP_OK;
 }
 
-// the exchange of the sorted costs (which = 0) or of the partial rows (which = 1), direct form
-int peer_push(lmcma_hip_ctx *c, int which)
+// where this shard's block of exchange `which` (0: sorted costs, 1: its row) goes: every peer's
+// mailbox, and for the row the own mailbox too (the costs' own block never leaves the context)
+PeerSend peer_send_table(const lmcma_hip_ctx *c, int which)
 {
     PeerSend s{};
     const int row = c->N + 2;
     for (int r = 0; r < c->world; ++r) {
-        if (which == 0 && r == c->rank) continue;  // the local ranking wrote the own block in place
+        if (which == 0 && r == c->rank) continue;
         char *base = static_cast<char *>(r == c->rank ? c->mailbox : c->peer_base[r]);
+        // (an image of this shard stands in for shard r: the block lands in r's place of the own mailbox)
+        const int from = (c->peer_image && r != c->rank) ? r : c->rank;
         const int d = s.n++;
         if (which == 0) {
-            s.dst[d] = mailbox_cost(base) + (size_t)c->rank * c->nloc;
-            s.flag[d] = mailbox_flags(base) + c->rank;
+            s.dst[d] = mailbox_cost(base) + (size_t)from * c->nloc;
+            s.flag[d] = mailbox_flags(base) + from;
         } else {
-            s.dst[d] = mailbox_rows(base, c->lambda) + (size_t)c->rank * row;
-            s.flag[d] = r == c->rank ? nullptr : mailbox_flags(base) + kMailboxRowFlags + c->rank;
+            s.dst[d] = mailbox_rows(base, c->lambda) + (size_t)from * row;
+            s.flag[d] = r == c->rank ? nullptr : mailbox_flags(base) + kMailboxRowFlags + from;
         }
     }
-    if (s.n == 0) return LMCMA_HIP_OK;
-    const int parts = which == 0 ? kCostParts : 1;
-    const uint32_t *src = which == 0 ? reinterpret_cast<const uint32_t *>(c->cost_all + c->first)
-                                     : reinterpret_cast<const uint32_t *>(c->partial_local);
-    const int words = which == 0 ? c->nloc : 2 * row;
-    hipLaunchKernelGGL(k_peer_push, dim3(s.n * parts), dim3(256), 0, c->stream, s, src, words, parts);
+    return s;
+}
+
+PeerSend peer_send_table_if_sending(const lmcma_hip_ctx *c, int which)
+{
+    return (c->peer_on && c->peer_sending) ? peer_send_table(c, which) : PeerSend{};
+}
+
+// The exchange of the sorted costs: one launch sends this shard's list and receives the peers'.
+int peer_exchange_costs(lmcma_hip_ctx *c)
+{
+    const PeerSend s = peer_send_table(c, 0);
+    const int quads = c->lambda / 4, own0 = c->first / 4;   // (lambda_local is a multiple of 64)
+    const int blocks = std::min(32, (std::max(s.n * (c->nloc / 4), quads) + 255) / 256);
+    PeerWait &w = c->wait_costs;
+    w.want = c->sent_costs += (uint32_t)blocks;
+    hipLaunchKernelGGL(k_peer_exchange, dim3(blocks), dim3(256), 0, c->stream, s,
+                       reinterpret_cast<const ulonglong2 *>(c->cost_all + c->first), c->nloc / 4, w,
+                       reinterpret_cast<const uint4 *>(mailbox_cost(c->mailbox)), reinterpret_cast<uint4 *>(c->cost_all),
+                       quads, own0, own0 + c->nloc / 4);
     HIP_TRY(hipGetLastError());
-    PeerWait &w = which == 0 ? c->wait_costs : c->wait_rows;
-    w.want = c->peer_epoch * (uint32_t)parts;
-    if (c->peer_wait_kernels) {
-        hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, c->stream, w);
-        HIP_TRY(hipGetLastError());
-    }
+    return LMCMA_HIP_OK;
+}
+
+// The receiving side of the exchange of the rows, queued behind the kernel that sent this shard's
+// (`arrivals` counter increments per source): wait for the peers, then mailbox -> partial_all.
+int peer_receive_rows(lmcma_hip_ctx *c, int arrivals)
+{
+    PeerWait &w = c->wait_rows;
+    w.want = c->sent_rows += (uint32_t)arrivals;
+    const int quads = (c->world * (c->N + 2) * (int)sizeof(double) + 15) / 16;   // (both buffers end in slack)
+    hipLaunchKernelGGL(k_peer_gather, dim3(std::min(8, (quads + 255) / 256)), dim3(256), 0, c->stream, w,
+                       reinterpret_cast<const uint4 *>(mailbox_rows(c->mailbox, c->lambda)),
+                       reinterpret_cast<uint4 *>(c->partial_all), quads);
+    HIP_TRY(hipGetLastError());
     return LMCMA_HIP_OK;
 }
 
@@ -1833,21 +1861,29 @@ int shard_stretch_local(lmcma_hip_ctx *c, bool update_due)
 int sharded_generation(lmcma_hip_ctx *c, const RcclApi *api, bool update_due = false, bool leave_update = false)
 {
     const int row = c->N + 2;
+    // direct exchange: the kernels that produce the shard's two blocks store them into the peers'
+    // mailboxes themselves where that pays (do_recombine_final looks at peer_sending)
+    c->peer_sending = c->peer_on;
+    c->peer_arrivals = 0;
     int rc = shard_stretch_local(c, update_due);
-    if (rc != LMCMA_HIP_OK) return rc;
-    if (c->peer_on) {
+    if (rc == LMCMA_HIP_OK && c->peer_on) {
         ++c->peer_epoch;
-        if ((rc = peer_push(c, 0)) != LMCMA_HIP_OK) return rc;
-    } else {
+        // (the ranking scatters its list four bytes at a time: sent from there, 28 000 small stores
+        // into uncached memory made that launch 24 us instead of 7)
+        rc = peer_exchange_costs(c);
+    } else if (rc == LMCMA_HIP_OK) {
         // in place: this shard's block lies at its offset inside the buffer of all costs
         RCCL_TRY(api, api->AllGather(c->cost_all + c->first, c->cost_all, (size_t)c->nloc, ncclFloat32, c->comm, c->stream));
     }
-    if ((rc = lmcma_hip_phase_rank(c)) != LMCMA_HIP_OK) return rc;
-    if (c->peer_on) {
-        if ((rc = peer_push(c, 1)) != LMCMA_HIP_OK) return rc;
-    } else {
+    c->peer_arrivals = 0;
+    if (rc == LMCMA_HIP_OK) rc = lmcma_hip_phase_rank(c);
+    if (rc == LMCMA_HIP_OK && c->peer_on) {
+        rc = peer_receive_rows(c, c->peer_arrivals);
+    } else if (rc == LMCMA_HIP_OK) {
         RCCL_TRY(api, api->AllGather(c->partial_local, c->partial_all, (size_t)row, ncclFloat64, c->comm, c->stream));
     }
+    c->peer_sending = false;
+    if (rc != LMCMA_HIP_OK) return rc;
     return leave_update ? LMCMA_HIP_OK : lmcma_hip_phase_update(c, c->world);
 }
 
@@ -1872,11 +1908,6 @@ int lmcma_hip_peer_handle(lmcma_hip_ctx *c, char handle[LMCMA_HIP_PEER_HANDLE_BY
     h.bytes = c->mailbox_bytes;
     h.lambda = c->lambda;
     h.N = c->N;
-    {
-        char bus[64] = {0};
-        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), c->cfg.device) != hipSuccess) (void)hipGetLastError();
-        strncpy(h.bus, bus, sizeof(h.bus) - 1);
-    }
     // (a process that only talks to itself needs no IPC handle; a failure here surfaces when another process opens it)
     if (hipIpcGetMemHandle(&h.ipc, c->mailbox) != hipSuccess) {
         (void)hipGetLastError();
@@ -1900,12 +1931,9 @@ int lmcma_hip_peer_disconnect(lmcma_hip_ctx *c)
     }
     if (c->peer_mapped) {
         drop_graph(c);
-        if (c->peer_on) {
-            c->cost_all = c->arena_cost_all;
-            c->partial_all = c->arena_partial_all;
-        }
         c->peer_on = false;
         c->peer_mapped = false;
+        c->peer_image = false;
         c->wait_costs = PeerWait{};
         c->wait_rows = PeerWait{};
         if (!c->comm) { c->world = 0; c->rank = 0; }
@@ -1925,13 +1953,9 @@ int lmcma_hip_peer_connect(lmcma_hip_ctx *c, const char *handles, int world, int
     if (c->comm && (c->world != world || c->rank != rank))
         return fail(LMCMA_HIP_ERR_ARG, "peer_connect: world / rank differ from the communicator's");
     HIP_TRY(hipStreamSynchronize(c->stream));
-    PeerHandle own;
-    memcpy(&own, handles + (size_t)rank * LMCMA_HIP_PEER_HANDLE_BYTES, sizeof(own));
-    int on_my_gpu = 0;
     for (int r = 0; r < world; ++r) {
         PeerHandle h;
         memcpy(&h, handles + (size_t)r * LMCMA_HIP_PEER_HANDLE_BYTES, sizeof(h));
-        if (h.magic == kPeerMagic && strncmp(h.bus, own.bus, sizeof(h.bus)) == 0) ++on_my_gpu;
         if (h.magic != kPeerMagic || h.lambda != c->lambda || h.N != c->N || h.bytes != c->mailbox_bytes) {
             (void)lmcma_hip_peer_disconnect(c);
             return fail(LMCMA_HIP_ERR_ARG, "peer_connect: handle " + std::to_string(r) + " is not the handle of a shard of this population");
@@ -1941,6 +1965,13 @@ int lmcma_hip_peer_connect(lmcma_hip_ctx *c, const char *handles, int world, int
                 (void)lmcma_hip_peer_disconnect(c);
                 return fail(LMCMA_HIP_ERR_ARG, "peer_connect: handle `rank` is not this context's");
             }
+            continue;
+        }
+        if (h.pid == (int32_t)getpid() && h.ptr == (uint64_t)(uintptr_t)c->mailbox) {
+            // this context's own handle in another shard's place: an image of itself (a measurement
+            // aid: one shard timed with the exchange traffic and the waits of a population of `world`)
+            c->peer_base[r] = c->mailbox;
+            c->peer_image = true;
             continue;
         }
         if (h.pid == (int32_t)getpid()) {
@@ -1970,11 +2001,6 @@ int lmcma_hip_peer_connect(lmcma_hip_ctx *c, const char *handles, int world, int
         }
     }
     drop_graph(c);
-    // from here on the buffers of all costs and of all rows are the mailbox's
-    c->arena_cost_all = c->cost_all;
-    c->arena_partial_all = c->partial_all;
-    c->cost_all = mailbox_cost(c->mailbox);
-    c->partial_all = mailbox_rows(c->mailbox, c->lambda);
     uint32_t *flags = mailbox_flags(c->mailbox);
     c->wait_costs = PeerWait{flags, 0u, world, rank, flags + kMailboxError};
     c->wait_rows = PeerWait{flags + kMailboxRowFlags, 0u, world, rank, flags + kMailboxError};
@@ -1984,12 +2010,6 @@ int lmcma_hip_peer_connect(lmcma_hip_ctx *c, const char *handles, int world, int
     c->rank = rank;
     c->peer_on = true;
     c->peer_mapped = true;
-    // Shards that share a GPU (a rehearsal): a kernel that waits for a peer holds its share of the
-    // device while the peer's kernels need room to run, and consumers that wait in every workgroup
-    // (the merge, the sampling launch that carries the update) can fill the device between them.
-    // Beyond small shards the waits then become one-wave launches of their own ahead of the
-    // consumers.  One shard per GPU: the consumers wait themselves, one launch boundary fewer.
-    c->peer_wait_kernels = on_my_gpu > 1 && (long)c->nloc * on_my_gpu > 2048;
     return LMCMA_HIP_OK;
 }
 
@@ -2000,13 +2020,6 @@ int lmcma_hip_peer_enable(lmcma_hip_ctx *c, int on)
     if ((on != 0) == c->peer_on) return LMCMA_HIP_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
     drop_graph(c);
-    if (on) {
-        c->cost_all = mailbox_cost(c->mailbox);
-        c->partial_all = mailbox_rows(c->mailbox, c->lambda);
-    } else {
-        c->cost_all = c->arena_cost_all;
-        c->partial_all = c->arena_partial_all;
-    }
     c->peer_on = on != 0;
     return LMCMA_HIP_OK;
 }

@@ -51,6 +51,29 @@ __device__ __forceinline__ void peer_wait(const PeerWait &w)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
+// ---- direct exchange: the producer's side (PeerSend) --------------------------------------
+// A store into a peer's mailbox: write-through at system scope.  Nothing of it stays in this
+// device's caches, so once the stores have been acknowledged (the wait in peer_arrive) they are in
+// the peer's memory, and no write-back of this device's L2 is needed before the counter moves (a
+// release fence would order one: every workgroup of a producer then walks the L2, which costs tens
+// of microseconds per launch).
+template <typename T>
+__device__ __forceinline__ void peer_store(T *p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Called by every thread of a workgroup after its peer_store calls: the workgroup's part of the
+// block is on its way, the destinations' arrival counters move by one.
+__device__ __forceinline__ void peer_arrive(const PeerSend &s)
+{
+    __builtin_amdgcn_s_waitcnt(0);                          // this lane's stores have been acknowledged
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (and the compiler moves nothing across)
+    __syncthreads();
+    if ((int)threadIdx.x < s.n && s.flag[threadIdx.x] != nullptr)
+        __hip_atomic_fetch_add(s.flag[threadIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- counter-based normals ---------------------------------------------------------
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,

@@ -20,11 +20,15 @@ struct Batch {
 
 // ---- direct exchange between the shards of a population ------------------------------------
 // Every shard owns a "mailbox" in fine-grained device memory that its peers can write (mapped
-// through IPC handles, or plain pointers inside one process): the buffer of all sorted costs, the
-// buffer of all partial rows, and one arrival counter per source and exchange.  A producer stores
-// its block into every peer's mailbox, makes the stores visible at system scope and adds 1 to its
-// counter there; the consuming kernel waits at its head until every other source's counter has
-// reached the value this exchange brings it to.  Counters only grow (wrap-around compare).
+// through IPC handles, or plain pointers inside one process): room for all sorted costs and all
+// partial rows, and one arrival counter per source and exchange.  A producer stores its block into
+// every peer's mailbox, makes the stores visible at system scope and adds 1 to its counter there.
+// On the receiving side a small launch (k_peer_gather) waits until every other source's counter
+// has reached the value this exchange brings it to and copies the blocks into the context's
+// ordinary buffers, which the consuming kernels then read as they read them after an all-gather
+// (reads of fine-grained memory are not cached: the merge of the sorted lists took 16 us instead
+// of 7 reading the mailbox itself, the update at the head of the sampling launch 30 instead of 15).
+// Counters only grow (wrap-around compare).
 constexpr int kMaxPeerRanks = 16;
 
 struct PeerWait {
@@ -38,7 +42,9 @@ struct PeerWait {
 
 struct PeerSend {
     // destination d of n: where this shard's block goes in that mailbox, and the counter to bump
-    // (null: the shard's own copy, which needs no counter)
+    // (null: the shard's own copy, which needs no counter).  The kernel that produces the block
+    // stores it there itself; every one of its workgroups that holds a part of the block adds 1 to
+    // the counters when its part is on its way (`arrivals` workgroups per exchange).
     void *dst[kMaxPeerRanks];
     uint32_t *flag[kMaxPeerRanks];
     int n;
@@ -217,7 +223,6 @@ struct MergeArgs {
     const double *weights;
     int mu;
     double *block_partials;
-    PeerWait wait;                // the lists arrive through the direct exchange (flags null: they are there)
 };
 bool rank_merge_possible(int lambda, int n_local, int first_candidate);
 // tile length for ranking a whole population in one context by tiles + merge, 0: not this way
@@ -241,11 +246,14 @@ struct FinalExtras {
     const unsigned long long *psr_accum;
     int count_psr;
     const float *best;
+    // the finished row (N + 2 entries) also goes into these mailboxes; *arrivals_out = workgroups
+    // that bump each destination's counter.  n = 0: nowhere.
+    PeerSend send;
 };
 // threads: the workgroup size whose summation order the result must have (a row that feeds the
 // context's own update: the update's); 0: any fixed order will do (a row that goes into an exchange)
 hipError_t launch_recombine_final(hipStream_t s, const double *block_partials, int rows, int N,
-                                  double *partial_local, int threads, const FinalExtras *extras);
+                                  double *partial_local, int threads, const FinalExtras *extras, int *arrivals_out = nullptr);
 // The sum over many partial rows, ahead of the update: rows -> reduce_rows_out(rows, N) <=
 // kReducedRowsMax rows of dst (one row for even N); used above kReduceRowsFrom rows.
 constexpr int kReducedRowsMax = 32;
@@ -278,7 +286,6 @@ struct UpdateArgs {
     float *xmean_f;             // [ld]
     float *V_f, *B_f;           // [m][ld] in iterator order, B = M^(k-1-t) nj pc
     Batch batch;
-    PeerWait wait;              // the partial rows arrive through the direct exchange (flags null: they are there)
 };
 hipError_t launch_update(hipStream_t s, const UpdateArgs &a);
 // The update in two launches (update_body.hpp): vectors that do not depend on this generation's

@@ -676,7 +676,6 @@ struct RankMergeArgs {
     int mu;
     double *block_partials;       // [gridDim.x][N]
     int owners;                   // 1, or G: this launch ranks the elements of every list (see MergeArgs)
-    PeerWait wait;                // the other contexts' lists arrive through the direct exchange
 };
 
 constexpr int kMergeChunk = 32768;  // the longest list; also the largest population one context ranks in tiles
@@ -790,7 +789,6 @@ __global__ __launch_bounds__(TB) void k_rank_merge(const RankMergeArgs r)
     const int p = grp < CPB / 2 ? bx * (CPB / 2) + grp : nl - (bx + 1) * (CPB / 2) + (grp - CPB / 2);
     const bool live = p < nl;
     const int pc = live ? p : nl - 1;
-    peer_wait(r.wait);
     const uint32_t mine = order_bits(r.lists[(size_t)me * nl + pc]);
     const uint32_t yprev = psr ? r.prev_own[own0 + pc] : 0u;
     const int cand = r.local_perm[own0 + pc];
@@ -1038,7 +1036,6 @@ hipError_t launch_rank_merge(hipStream_t s, const MergeArgs &a, int *rows_out)
     r.weights = a.weights; r.mu = a.mu;
     r.block_partials = a.block_partials;
     r.owners = a.owners > 1 ? a.owners : 1;
-    r.wait = a.wait;
     if (r.owners > 1 && (r.owners != a.lambda / a.n_local || a.first_candidate != 0)) return hipErrorInvalidValue;
     const int blocks = r.owners * ((a.n_local + 31) / 32);
     if (rows_out) *rows_out = blocks;

@@ -66,7 +66,11 @@ __global__ __launch_bounds__(1024) void k_recombine_final(const double *__restri
     __shared__ double s_red[2048];  // row_sum_lds_doubles(N <= 512, T <= 1024)
     row_sums_to_lds(block_partials, nblocks, N, N, (int)blockDim.x, s_red);
     __syncthreads();
-    for (int n = threadIdx.x; n < N; n += blockDim.x) partial_local[n] = row_sums_total(s_red, N, n, row_sum_groups(N, (int)blockDim.x));
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const double total = row_sums_total(s_red, N, n, row_sum_groups(N, (int)blockDim.x));
+        partial_local[n] = total;
+        for (int d = 0; d < x.send.n; ++d) peer_store(static_cast<double *>(x.send.dst[d]) + n, total);
+    }
     if (x.best != nullptr && threadIdx.x < 64) {
         unsigned long long v = 0ull;
         if (x.count_psr) {
@@ -76,10 +80,16 @@ __global__ __launch_bounds__(1024) void k_recombine_final(const double *__restri
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
         if (threadIdx.x == 0) {
+            const double best = (double)*x.best;
             partial_local[N] = (double)v;
-            partial_local[N + 1] = (double)*x.best;
+            partial_local[N + 1] = best;
+            for (int d = 0; d < x.send.n; ++d) {
+                peer_store(static_cast<double *>(x.send.dst[d]) + N, (double)v);
+                peer_store(static_cast<double *>(x.send.dst[d]) + N + 1, best);
+            }
         }
     }
+    if (x.send.n > 0) peer_arrive(x.send);
 }
 
 // The same sum by several workgroups, 16 columns each, for a row that leaves the context (a shard's
@@ -122,6 +132,7 @@ __global__ __launch_bounds__(256) void k_recombine_final_wide(const double *bloc
         double total = 0.0;
         for (int q = 0; q < 32; ++q) total += s_red[q][tid];
         partial_local[16 * blockIdx.x + tid] = total;
+        for (int d = 0; d < x.send.n; ++d) peer_store(static_cast<double *>(x.send.dst[d]) + 16 * blockIdx.x + tid, total);
     }
     if (blockIdx.x == 0 && x.best != nullptr && tid >= 64 && tid < 128) {
         const int l = tid - 64;
@@ -133,10 +144,16 @@ __global__ __launch_bounds__(256) void k_recombine_final_wide(const double *bloc
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
         if (l == 0) {
+            const double best = (double)*x.best;
             partial_local[N] = (double)v;
-            partial_local[N + 1] = (double)*x.best;
+            partial_local[N + 1] = best;
+            for (int d = 0; d < x.send.n; ++d) {
+                peer_store(static_cast<double *>(x.send.dst[d]) + N, (double)v);
+                peer_store(static_cast<double *>(x.send.dst[d]) + N + 1, best);
+            }
         }
     }
+    if (x.send.n > 0) peer_arrive(x.send);  // (uniform over the launch)
 }
 
 // A first level for many partial rows: rows [b chunk, (b + 1) chunk) of src -> row b of dst.
@@ -278,13 +295,15 @@ hipError_t launch_reduce_rows(hipStream_t s, const double *src, int rows, int N,
 }
 
 hipError_t launch_recombine_final(hipStream_t s, const double *block_partials, int rows, int N,
-                                  double *partial_local, int threads, const FinalExtras *extras)
+                                  double *partial_local, int threads, const FinalExtras *extras, int *arrivals_out)
 {
     if (rows < 1 || N < 1) return hipErrorInvalidValue;
     FinalExtras x{};
     if (extras) x = *extras;
+    if (arrivals_out) *arrivals_out = 1;
     if (threads == 0) {  // the caller leaves the summation order to this function
         if ((N & 1) == 0 && rows >= 32) {
+            if (arrivals_out) *arrivals_out = (N + 15) / 16;
             hipLaunchKernelGGL(k_recombine_final_wide, dim3((N + 15) / 16), dim3(256), 0, s, block_partials, rows, N,
                                partial_local, x, (size_t)0);
             return hipGetLastError();

@@ -288,7 +288,6 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, double *s_dyn, 
             pcold[q] = a.pc[n];
         }
     }
-    peer_wait(a.wait);  // (a sharded population with the direct exchange: the rows of the other shards)
     // success-rule count (the sum over this generation's candidates of the number of last
     // generation's costs below it): one wave reads the per-workgroup shares, up to 1024 of them
     uint32_t pp[16];
@@ -1029,7 +1028,6 @@ __device__ __forceinline__ bool update_post_body(const UpdateArgs &a, double *s_
             pcold[q] = a.pc[n];
         }
     }
-    peer_wait(a.wait);  // (a sharded population with the direct exchange: the rows of the other shards)
     uint32_t pp[16];
     unsigned long long psr_lane = 0ull;
     float best_in = 0.f;
