@@ -639,8 +639,6 @@ int generations(lmcma_hip_ctx *c, int n)
     return n > 0 ? do_update(c, src, rows, false) : LMCMA_HIP_OK;
 }
 
-int one_generation(lmcma_hip_ctx *c) { return generations(c, 1); }
-
 int check_ctx(const lmcma_hip_ctx *c)
 {
     if (!c) return fail(LMCMA_HIP_ERR_ARG, "null context");
@@ -1360,7 +1358,8 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
     if (!c->grid) return fail(LMCMA_HIP_ERR_STATE, "set_grid must come first");
     if (n_generations < 0) return fail(LMCMA_HIP_ERR_ARG, "negative generation count");
     int left = n_generations;
-    const bool use_graph = !c->timing && getenv("LMCMA_HIP_NO_GRAPH") == nullptr;
+    static const bool no_graph = getenv("LMCMA_HIP_NO_GRAPH") != nullptr;  // (read once, not per call)
+    const bool use_graph = !c->timing && !no_graph;
     if (use_graph && left > 0 && !c->graph_exec[0][0]) {
         // The graphs are recorded on the first call, whatever its length, so that no later call
         // pays for it: one eager generation first (module load and LDS attribute calls stay out
@@ -1369,10 +1368,13 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
         // only: none of the recorded generations has run, and the host-side bookkeeping they went
         // through (the buffer parity, pre_done) is put back to where it was.
         if (!c->warmed) {
-            int rc = one_generation(c);
+            // (two when the call has them: the sampling launch that carries an update only runs
+            // between two generations of one call, and a capture must not be its first launch)
+            const int w = left >= 2 ? 2 : 1;
+            int rc = generations(c, w);
             if (rc != LMCMA_HIP_OK) return rc;
-            --left;
-            c->warmed = true;
+            left -= w;
+            c->warmed = w == 2;
         }
         for (int q = 0; q < kGraphKinds; ++q) c->graph_gens[q] = kGensPerGraphDefault[q];
         if (const char *e = getenv("LMCMA_HIP_GRAPH_GENS")) {

@@ -687,8 +687,11 @@ hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds, const Upd
     // 256-thread workgroups fit, the wide one gains nothing: N = 144 and 256 measured).
     bool wide = J >= 2 && vb_lds && !cov && !grid_lds && 2 * kTile * row_b + vb_b <= budget &&
                 2 * (rows_b + vb_b) > budget;
-    if (const char *f = getenv("LMCMA_HIP_GENERATE_THREADS"))
-        wide = J >= 2 && vb_lds && !cov && !grid_lds && 2 * kTile * row_b + vb_b <= budget && atoi(f) == 512;
+    // (measurement switches are read once per process, not per launch)
+    static const int forced_threads = getenv("LMCMA_HIP_GENERATE_THREADS") ? atoi(getenv("LMCMA_HIP_GENERATE_THREADS")) : 0;
+    static const int forced_batch_blocks = getenv("LMCMA_HIP_BATCH_BLOCKS") ? atoi(getenv("LMCMA_HIP_BATCH_BLOCKS")) : 0;
+    if (forced_threads != 0)
+        wide = J >= 2 && vb_lds && !cov && !grid_lds && 2 * kTile * row_b + vb_b <= budget && forced_threads == 512;
     const int tile = wide ? 2 * kTile : kTile;
     if (wide) rows_b = tile * row_b;
     const int ntiles = (g.n_local + tile - 1) / tile;
@@ -702,7 +705,7 @@ hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds, const Upd
     // workgroup's staged vectors serve several tiles (about eight workgroups per CU over the launch)
     if (g.batch.queries > 1) {
         int per_query = kBatchBlocks / g.batch.queries;
-        if (const char *f = getenv("LMCMA_HIP_BATCH_BLOCKS")) per_query = atoi(f) / g.batch.queries;
+        if (forced_batch_blocks != 0) per_query = forced_batch_blocks / g.batch.queries;
         blocks = std::min(blocks, std::max(per_query, 1));
     }
     // Many queries in one launch: the products on the matrix cores (k_generate_mfma), when nothing
@@ -714,7 +717,7 @@ hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds, const Upd
         if (mlds <= budget) {
             const int mtiles = (g.n_local + kMfmaTile - 1) / kMfmaTile;
             int per_query = kBatchBlocks / g.batch.queries;
-            if (const char *f = getenv("LMCMA_HIP_BATCH_BLOCKS")) per_query = atoi(f) / g.batch.queries;
+            if (forced_batch_blocks != 0) per_query = forced_batch_blocks / g.batch.queries;
             const int mblocks = std::min(mtiles, std::max(per_query, 1));
             hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_generate_mfma<D>), mlds);
             if (e != hipSuccess) return e;

@@ -974,7 +974,8 @@ extern "C" hipError_t lmcma_diag_rank_stamps(unsigned long long *out16)
 
 bool select_by_counting(int lambda)
 {
-    return lambda <= kRankCountMax && getenv("LMCMA_HIP_SELECT_SORT") == nullptr;
+    static const bool forced_sort = getenv("LMCMA_HIP_SELECT_SORT") != nullptr;  // (read once, not per launch)
+    return lambda <= kRankCountMax && !forced_sort;
 }
 
 // candidates per workgroup of the counting path: 16 lanes each
@@ -984,10 +985,8 @@ int select_candidates_per_block(int lambda)
     // workgroup counts faster but leaves twice as many partial rows for the one-workgroup
     // update to read, a larger one the other way round)
     int threads = lambda >= 1024 ? 512 : 256;
-    if (const char *f = getenv("LMCMA_HIP_RANK_THREADS")) {
-        const int v = atoi(f);
-        if (v == 256 || v == 512 || v == 1024) threads = v;
-    }
+    static const int forced = getenv("LMCMA_HIP_RANK_THREADS") ? atoi(getenv("LMCMA_HIP_RANK_THREADS")) : 0;
+    if (forced == 256 || forced == 512 || forced == 1024) threads = forced;
     return threads / 16;
 }
 
@@ -1012,14 +1011,17 @@ int rank_tile_len(int lambda)
 
 bool rank_merge_possible(int lambda, int n_local, int first_candidate)
 {
+    static const bool no_merge = getenv("LMCMA_HIP_NO_MERGE_RANK") != nullptr;
     // (the pivots of all lists, lambda / 16 keys, have to fit in LDS beside the row sums)
     return n_local < lambda && n_local % 64 == 0 && lambda % n_local == 0 && first_candidate % n_local == 0 &&
-           n_local <= kMergeChunk && lambda <= kMergeMaxLambda && getenv("LMCMA_HIP_NO_MERGE_RANK") == nullptr;
+           n_local <= kMergeChunk && lambda <= kMergeMaxLambda && !no_merge;
 }
 
 hipError_t launch_rank_merge(hipStream_t s, const MergeArgs &a, int *rows_out)
 {
-    if (!rank_merge_possible(a.lambda, a.n_local, a.first_candidate) && rank_tile_len(a.lambda) != a.n_local)
+    // (a context's own tiles: owners = lambda / n_local, checked below; a shard: the merge's limits)
+    if (a.owners <= 1 && !rank_merge_possible(a.lambda, a.n_local, a.first_candidate)) return hipErrorInvalidValue;
+    if (a.n_local < 64 || a.n_local % 64 != 0 || a.lambda % a.n_local != 0 || a.n_local > kMergeChunk || a.lambda > kMergeMaxLambda)
         return hipErrorInvalidValue;
     RankMergeArgs r{};
     r.lists = a.lists;

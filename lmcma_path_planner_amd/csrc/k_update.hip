@@ -218,10 +218,9 @@ extern "C" hipError_t lmcma_diag_update_stamps(unsigned long long *out16)
 static int threads_for_vectors(int m)
 {
     int t = m <= 16 ? 256 : m <= 32 ? 512 : 1024;
-    if (const char *f = getenv("LMCMA_HIP_UPDATE_THREADS")) {  // more threads than 16 m: they only help read the partial rows
-        const int v = atoi(f);
-        if ((v == 256 || v == 512 || v == 1024) && v >= t) t = v;
-    }
+    // (a measurement switch, read once: more threads than 16 m only help read the partial rows)
+    static const int v = getenv("LMCMA_HIP_UPDATE_THREADS") ? atoi(getenv("LMCMA_HIP_UPDATE_THREADS")) : 0;
+    if ((v == 256 || v == 512 || v == 1024) && v >= t) t = v;
     return t;
 }
 

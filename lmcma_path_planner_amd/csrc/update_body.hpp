@@ -1119,9 +1119,12 @@ __device__ __forceinline__ bool update_post_body(const UpdateArgs &a, double *s_
         if (lane == 0) s_ljp[pos] = lj_old;
     }
     row_sums_to_lds_t<true>(a.partials, a.n_partials, N, a.partial_stride, TR, s_red, first_rows);
+    // Workgroup 0 overwrites the state once every other workgroup has reported below, so every load
+    // of the old state issued above (mean, path, vectors: some are first used after this point) must
+    // have returned before the report: a barrier alone does not wait for outstanding global loads.
+    if (FUSED && !ws) __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     POST_STAMP(2);
-    // (every load of this workgroup has arrived: the barrier above waited for them)
     if (FUSED && !ws && tid == 0) __hip_atomic_fetch_add(fo->counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // L/:316-329: new mean, evolution path
     double xnew[2] = {0.0, 0.0}, pcn[2] = {0.0, 0.0};
@@ -1266,7 +1269,7 @@ __device__ __forceinline__ bool update_post_body(const UpdateArgs &a, double *s_
         if (tid == 0) {
             int spins = 0, ok = 1;
             while (__hip_atomic_load(fo->counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fo->others) {
-                if (++spins > (1 << 23)) {  // about a second: the exit every wave reaches whatever the others do
+                if (++spins > (1 << 23)) {  // some seconds: the exit every wave reaches whatever the others do
                     ok = 0;
                     break;
                 }
