@@ -29,7 +29,9 @@ Rank 0 prints one JSON line; besides the throughput it carries
                 stream around the timed steps), against the 8 TB/s HBM3E peak
   cpu_baseline  the CPU oracle (a port of the reference algorithm, fp64) on a bounded
                 sample of the same workload, candidates spread over the box's host
-                threads; cpu_baseline_1thread: the same on one thread.  N = 1 only
+                threads; cpu_baseline_1thread: the same on one thread;
+                cpu_baseline_reference: the reference's own compiled optimiser on one
+                thread (where oracle/_ref was built).  N = 1 only
 """
 import argparse
 import json
@@ -93,6 +95,34 @@ def cpu_baseline(prob, threads, budget_s):
     return {"value": prob.lam * gens / el, "unit": "candidate-trajectories/s", "cores": threads, "kind": "port",
             "sample": "%d generations of lambda=%d (%.1f s) of the same workload, fp64, %d host thread%s"
                       % (gens, prob.lam, el, threads, "" if threads == 1 else "s over the candidates")}
+
+
+def cpu_reference(prob, budget_s):
+    """The reference's own optimiser (its lmcma.cpp compiled where it lies into oracle/_ref, see
+    oracle/Makefile) driving its per-candidate ask/tell loop on one thread, with the oracle's fp64
+    trajectory cost as the caller's cost function.  The reference keeps as many direction vectors as
+    candidates (lmcma.cpp:266) and has no other mode, so what is timed is the first 32 generations of
+    fresh runs at this workload's shape, in which its store holds 1 .. 32 vectors (16.5 on average,
+    against the 16 of the configuration named); its own sequential generator draws the normals.
+    None when the library was not built (it exists only where the reference tree was present at
+    build time)."""
+    from oracle import pyoracle, pyref
+    if not pyref.available():
+        return None
+    import ctypes
+    co = pyoracle.CostOracle(prob.dims, prob.W, prob.cells, prob.start, prob.goal)
+    cb = ctypes.cast(pyoracle.load().orc_cost_callback, ctypes.c_void_p)
+    user = ctypes.cast(ctypes.byref(co.p), ctypes.c_void_p)
+    gens_per_run, runs, seconds = 32, 0, 0.0
+    while seconds < budget_s and runs < 64:
+        r = pyref.RefLMCMA(prob.N, prob.lam, initial=prob.x0, lo=prob.lo, hi=prob.hi, sigma=prob.sigma0, seed=42 + runs)
+        seconds += r.run_timed(cb, user, gens_per_run)
+        runs += 1
+    return {"value": prob.lam * gens_per_run * runs / seconds, "unit": "candidate-trajectories/s", "cores": 1,
+            "kind": "reference",
+            "sample": "%d fresh runs of the reference's LMCMA (m = lambda = %d, its only mode), the first %d generations "
+                      "each (1 to %d stored direction vectors), %.1f s, one thread, its own normal generator, fp64 cost"
+                      % (runs, prob.lam, gens_per_run, gens_per_run, seconds)}
 
 
 def batched_leg(hip, prob, lam, queries, steps):
@@ -482,6 +512,9 @@ def main():
             cores = host_threads()
             out["cpu_baseline"] = cpu_baseline(prob, cores, 12.0)
             out["cpu_baseline_1thread"] = cpu_baseline(prob, 1, 8.0)
+            ref = cpu_reference(prob, 8.0)
+            if ref is not None:
+                out["cpu_baseline_reference"] = ref
     alt = None
     if world > 1 and native and have_rccl and args.exchange == "peer":
         # the other exchange form on the same contexts, timed the same way (a shorter region)

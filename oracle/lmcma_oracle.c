@@ -821,6 +821,15 @@ double orc_cost(const orc_problem *p, const double *row, double *terms)
     return total;
 }
 
+/* the cost as a plain callback (problem, row, length): what a caller's loop around the
+ * reference's ask/tell interface evaluates between getNextParameterVector and
+ * setEvaluationFeedback (L/example_lmcma.cpp:51-54) */
+double orc_cost_callback(void *problem, const double *row, int n)
+{
+    (void)n;
+    return orc_cost((const orc_problem *)problem, row, NULL);
+}
+
 void orc_cost_rows_f32(const orc_problem *p, const float *rows, int count,
                        double *cost, double *terms)
 {

@@ -128,6 +128,7 @@ typedef struct {
 
 /* terms[0..2] = J_len, J_grid, J_smooth (unweighted); returns the weighted total */
 double orc_cost(const orc_problem *p, const double *row, double *terms);
+double orc_cost_callback(void *problem, const double *row, int n);
 void orc_lmcma_run_trajectory(orc_lmcma *o, const orc_problem *p, int generations);
 /* host threads for the loops over candidates (timed CPU baseline); default 1 */
 void orc_set_threads(int n);

@@ -113,6 +113,8 @@ def load():
         f.argtypes, f.restype = [vp], c_int_p
     L.orc_cost.argtypes = [ctypes.POINTER(ProblemC), c_double_p, c_double_p]
     L.orc_cost.restype = d
+    L.orc_cost_callback.argtypes = [vp, c_double_p, i]
+    L.orc_cost_callback.restype = d
     L.orc_cost_rows_f32.argtypes = [ctypes.POINTER(ProblemC), c_float_p, i, c_double_p, c_double_p]
     L.orc_lmcma_run_trajectory.argtypes = [vp, ctypes.POINTER(ProblemC), i]
     L.orc_set_threads.argtypes = [i]
