@@ -687,6 +687,25 @@ hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds, const Upd
     // 256-thread workgroups fit, the wide one gains nothing: N = 144 and 256 measured).
     bool wide = J >= 2 && vb_lds && !cov && !grid_lds && 2 * kTile * row_b + vb_b <= budget &&
                 2 * (rows_b + vb_b) > budget;
+    // The update's first part rides as one more workgroup (below).  Where the 256-thread workgroups
+    // fill the machine exactly (lambda = 8192, N = 144, m = 32: 70 KB of LDS each, two per CU, 512 of
+    // them), that extra workgroup displaces one of them into a second round, and the launch takes
+    // 21.8 us instead of 16.5 however short the first part is (halving its chain of steps left the
+    // launch at 21.8 us).  The 512-thread form has half as many workgroups: if they and the extra one
+    // are all resident at once, it is the better shape (cfg3: 47.8 -> 45.5 us per generation; at
+    // N = 256 a 512-thread workgroup needs 81 KB, one per CU, and nothing is gained: 54.6 against 50.9).
+    static const bool no_pre_switch = getenv("LMCMA_HIP_UPDATE_ONE_KERNEL") != nullptr;
+    const bool pre_rides = pre && !no_pre_switch && !cov && !grid_lds && pre->m <= 32 && pre_emax_for(J, pre->N) > 0 &&
+                           update_emax(pre->N) <= pre_emax_for(J, pre->N) && update_is_split(pre->N, pre->m) &&
+                           !update_pre_rides_with_ranking(pre->m);
+    if (pre_rides && !wide && J >= 2 && vb_lds && g.batch.queries == 1) {
+        const size_t lds_narrow = rows_b + vb_b, lds_wide = 2 * kTile * row_b + vb_b;
+        const int blocks_narrow = std::min((g.n_local + kTile - 1) / kTile, 512);
+        const int blocks_wide = std::min((g.n_local + 2 * kTile - 1) / (2 * kTile), 256);
+        const int slots_narrow = 256 * (int)std::min<size_t>(budget / lds_narrow, 8);   // (256 threads: 8 workgroups of waves per CU)
+        const int slots_wide = lds_wide <= budget ? 256 * (int)std::min<size_t>(budget / lds_wide, 4) : 0;
+        if (blocks_narrow + 1 > slots_narrow && blocks_wide + 1 <= slots_wide) wide = true;
+    }
     // (measurement switches are read once per process, not per launch)
     static const int forced_threads = getenv("LMCMA_HIP_GENERATE_THREADS") ? atoi(getenv("LMCMA_HIP_GENERATE_THREADS")) : 0;
     static const int forced_batch_blocks = getenv("LMCMA_HIP_BATCH_BLOCKS") ? atoi(getenv("LMCMA_HIP_BATCH_BLOCKS")) : 0;
@@ -735,9 +754,7 @@ hipError_t launch_jd(hipStream_t s, const GenParams &g, bool grid_lds, const Upd
     }
     // the first part of the update as one more workgroup (see k_generate): stores of 17 to 32
     // vectors whose register tile exists for this row length
-    static const bool no_pre = getenv("LMCMA_HIP_UPDATE_ONE_KERNEL") != nullptr;
-    if (pre && !no_pre && pre->m <= 32 && pre_emax_for(J, pre->N) > 0 && update_emax(pre->N) <= pre_emax_for(J, pre->N) &&
-        update_is_split(pre->N, pre->m) && !update_pre_rides_with_ranking(pre->m)) {
+    if (pre_rides) {
         if (pre_done) *pre_done = true;
         if (J >= 2 && wide) return launch_t<J, D, false, true, false, true, (J >= 2 ? 512 : 256)>(s, g, lds, blocks, pre);
         if (vb_lds) return launch_t<J, D, false, true, false, true>(s, g, lds, blocks, pre);
