@@ -2260,6 +2260,16 @@ int lmcma_hip_stream_elapsed(lmcma_hip_ctx *c, double *ms)
 hipError_t lmcma_diag_update_stamps(unsigned long long *out16);
 hipError_t lmcma_diag_rank_stamps(unsigned long long *out16);
 hipError_t lmcma_diag_generate_stamps(unsigned long long *out16);
+hipError_t lmcma_diag_set_skip_report(int on);
+// on != 0: one workgroup of every sampling launch that carries the update withholds its report, so
+// the storing workgroup's bounded wait gives up (lmcma_hip_opt_get then returns the error)
+int lmcma_hip_diag_skip_report(lmcma_hip_ctx *c, int on)
+{
+    CTX_TRY(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(lmcma_diag_set_skip_report(on));
+    return LMCMA_HIP_OK;
+}
 // which = 0: stamps of the update kernel, 1: of the ranking kernel, 2: of the generation kernel
 int lmcma_hip_diag_stamps(lmcma_hip_ctx *c, int which, unsigned long long *out16)
 {

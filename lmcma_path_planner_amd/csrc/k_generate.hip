@@ -808,6 +808,10 @@ extern "C" hipError_t lmcma_diag_generate_stamps(unsigned long long *out16)
 {
     return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_generate_stamps), 16 * sizeof(unsigned long long));
 }
+extern "C" hipError_t lmcma_diag_set_skip_report(int on)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_diag_skip_report), &on, sizeof(int));
+}
 #endif
 
 bool generate_fuses(const GenParams &g, bool grid_lds, const UpdateArgs *post) { return generate_can_fuse(g, grid_lds, post); }

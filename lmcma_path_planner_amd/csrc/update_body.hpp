@@ -205,6 +205,9 @@ __device__ __forceinline__ int wave_min_i32(int v)
 #ifdef LMCMA_DIAG
 // diagnostic build only: wall-clock stamps (100 MHz counter) of kernel phases
 static __device__ unsigned long long g_update_stamps[16];
+// != 0: workgroup 1 of a sampling launch that carries the update does not report to workgroup 0,
+// whose wait then gives up (the path a test has to be able to force)
+static __device__ int g_diag_skip_report;
 #define LMCMA_STAMP(i)                                                                    \
     do {                                                                                  \
         if (threadIdx.x == 0) g_update_stamps[i] = __builtin_amdgcn_s_memrealtime();      \
@@ -1125,7 +1128,12 @@ __device__ __forceinline__ bool update_post_body(const UpdateArgs &a, double *s_
     if (FUSED && !ws) __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     POST_STAMP(2);
-    if (FUSED && !ws && tid == 0) __hip_atomic_fetch_add(fo->counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef LMCMA_DIAG
+    if (FUSED && !ws && tid == 0 && !(g_diag_skip_report != 0 && blockIdx.x == 1))
+#else
+    if (FUSED && !ws && tid == 0)
+#endif
+        __hip_atomic_fetch_add(fo->counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // L/:316-329: new mean, evolution path
     double xnew[2] = {0.0, 0.0}, pcn[2] = {0.0, 0.0};
 #pragma unroll
@@ -1269,7 +1277,11 @@ __device__ __forceinline__ bool update_post_body(const UpdateArgs &a, double *s_
         if (tid == 0) {
             int spins = 0, ok = 1;
             while (__hip_atomic_load(fo->counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fo->others) {
+#ifdef LMCMA_DIAG
+                if (++spins > (1 << 16)) {  // (the diagnostic build gives up after some tens of milliseconds)
+#else
                 if (++spins > (1 << 23)) {  // some seconds: the exit every wave reaches whatever the others do
+#endif
                     ok = 0;
                     break;
                 }

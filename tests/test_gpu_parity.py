@@ -1077,3 +1077,67 @@ def test_stepwise_api_with_the_reference_choice_m_equal_lambda(hip, oracle):
     with pytest.raises(LmcmaError, match="at most 64"):
         ctx.opt_init(np.zeros(N), 1.0)
     ctx.close()
+
+
+GIVE_UP_SCRIPT = """
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from lmcma_path_planner_amd import _lib, grids, hip
+prob = grids.benchmark_problem(2)
+ctx = hip.HipContext(prob.N, prob.lam, prob.m, dims=2, waypoints=prob.W, start=prob.start, goal=prob.goal, seed=42)
+ctx.set_grid(prob.cells); ctx.set_bounds(prob.lo, prob.hi); ctx.opt_init(prob.x0, prob.sigma0)
+ctx.run(6)                                   # recorded graphs, the carried update among them: all well
+good = ctx.opt_get()
+vec = ctx.opt_vectors()
+lib = _lib.load()
+lib.lmcma_hip_diag_skip_report.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert lib.lmcma_hip_diag_skip_report(ctx._h, 1) == 0
+ctx.run(4)                                   # one workgroup withholds its report: the storing one gives up
+ctx.synchronize()
+try:
+    ctx.opt_get()
+    print("NO ERROR REPORTED")
+    sys.exit(1)
+except _lib.LmcmaError as e:
+    assert "gave up" in str(e), str(e)
+# what the failed update was to replace is intact: mean, step size, path, stored paths, slot tables of
+# generation 6 (the first part of the update, which ran with the ranking launch before, had already
+# rebuilt some vectors v_j and their nj, lj from the stored paths; they are re-derived by every update)
+sm = _lib.OptSummary()
+xm = np.empty(prob.N)
+rc = lib.lmcma_hip_opt_get(ctx._h, ctypes.byref(sm), xm.ctypes.data_as(_lib.c_double_p))
+assert rc != 0
+assert np.array_equal(xm, good["xmean"]), "the mean changed"
+after = ctx.opt_vectors()
+for k in ("pc", "pc_arr", "iterator"):
+    assert np.array_equal(vec[k], after[k]), k
+# a reset clears the mark and the context works again
+assert lib.lmcma_hip_diag_skip_report(ctx._h, 0) == 0
+ctx.opt_reset()
+ctx.run(5)
+st = ctx.opt_get()
+assert st["itr"] == 5 and np.isfinite(st["best_f"])
+print("give-up path: error reported, state intact, reset recovers")
+"""
+
+
+@pytest.mark.gpu
+def test_fused_update_give_up_path_reports_and_keeps_the_state():
+    """The sampling launch that carries the previous generation's update: its storing workgroup waits
+    (bounded) for every other workgroup's report before it overwrites the state.  In the diagnostic
+    build one workgroup can be made to withhold its report: the wait gives up, nothing is stored,
+    lmcma_hip_opt_get returns the error, what that update was to replace (mean, step size, paths, slot
+    tables of the last good generation) is still there, and lmcma_hip_opt_reset puts the context back
+    to work."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "lmcma_path_planner_amd", "lib", "liblmcma_hip_diag.so")
+    if not os.path.exists(diag):
+        pytest.skip("the diagnostic build (make -C lmcma_path_planner_amd/csrc diag) is not there")
+    env = dict(os.environ, LMCMA_HIP_LIB=diag)
+    out = subprocess.run([sys.executable, "-c", GIVE_UP_SCRIPT % root], env=env, capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "state intact" in out.stdout
