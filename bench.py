@@ -330,11 +330,37 @@ def main():
             if args.exchange == "peer":
                 # the mailboxes: every shard's handle to every shard, all mapped before anyone sends
                 handles = [None] * world
-                dist.all_gather_object(handles, ctx.peer_handle())
-                ctx.peer_connect(handles, rank)
-                dist.barrier()
+                problem = None
+                try:
+                    mine = ctx.peer_handle()
+                except Exception as e:      # (the library's error text says what was refused)
+                    mine, problem = None, str(e)
+                dist.all_gather_object(handles, mine)
+                if problem is None and all(h is not None for h in handles):
+                    try:
+                        ctx.peer_connect(handles, rank)
+                    except Exception as e:
+                        problem = str(e)
+                elif problem is None:
+                    problem = "another shard could not export its mailbox"
+                problems = [None] * world
+                dist.all_gather_object(problems, problem)
+                problems = [p for p in problems if p]
                 exchange_used = "peer"
-                if have_rccl:
+                if problems:
+                    # every shard or none: back to the communicator, or stop where there is none
+                    try:
+                        ctx.peer_disconnect()
+                    except Exception:
+                        pass
+                    if not have_rccl:
+                        raise SystemExit("the mailboxes of the direct exchange could not be set up: %s" % problems[0])
+                    exchange_used = "library"
+                    exchange_check = "the mailboxes could not be set up (%s): the RCCL form is what was timed" % problems[0]
+                dist.barrier()
+                if problems:
+                    pass
+                elif have_rccl:
                     # the direct exchange against the RCCL form on this very node: same bits, or RCCL it is
                     def probe():
                         ctx.opt_reset()
@@ -519,7 +545,7 @@ def main():
     if world > 1 and native and have_rccl and args.exchange == "peer":
         # the other exchange form on the same contexts, timed the same way (a shorter region)
         other_is_peer = exchange_used != "peer"
-        if not other_is_peer or exchange_check is None or "identical" in exchange_check:
+        if not other_is_peer:
             ctx.peer_enable(other_is_peer)
             k_alt = min(args.steps, 400)
             run_steps(100)
@@ -536,7 +562,7 @@ def main():
     if rank == 0:
         if alt is not None:
             out["exchange_alternative"] = alt
-        if world > 1 and args.exchange == "peer":
+        if world > 1 and exchange_used == "peer":
             out["peer_status"] = ctx.peer_status()
         print(json.dumps(out))
     if world > 1:

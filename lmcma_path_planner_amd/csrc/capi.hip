@@ -2161,7 +2161,7 @@ int lmcma_hip_opt_get(lmcma_hip_ctx *c, lmcma_hip_opt_summary *summary, double *
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (o.done == 3)
         return fail(LMCMA_HIP_ERR_RUNTIME, "an update gave up waiting for the other workgroups of its launch; the state is stale");
-    if (c->mailbox) {
+    if (c->mailbox && c->peer_on) {  // (a run that has gone back to the communicator is not held to an earlier failure)
         uint32_t err = 0;
         HIP_TRY(hipMemcpy(&err, static_cast<uint32_t *>(c->mailbox) + 128, sizeof(err), hipMemcpyDeviceToHost));
         if (err != 0)
