@@ -426,9 +426,11 @@ def main():
         if args.steps <= 256:
             # A short timed region is one library call.  Like any caller that steps K generations at
             # a time it has made that call before: the library keeps a graph of a call length it has
-            # seen, recorded behind the first such call and replayed from the second on (a graph's
-            # first launch costs more than its later ones, hence two rehearsals).
-            for _ in range(2):
+            # seen, recorded behind the first such call and replayed from the second on.  A graph's
+            # first two launches cost more than its later ones (tools/short_call.py, 20 generations:
+            # 522 and 508 us, then 496 from the third launch on), hence four rehearsals: the call that
+            # records and three replays.
+            for _ in range(4):
                 run_steps(args.steps)
                 fence()
     t0 = time.perf_counter()

@@ -12,17 +12,18 @@ ctx = hip.HipContext(prob.N, prob.lam, prob.m, dims=prob.dims, waypoints=prob.W,
 ctx.set_grid(prob.cells); ctx.set_bounds(prob.lo, prob.hi); ctx.opt_init(prob.x0, prob.sigma0)
 ctx.run(50); ctx.synchronize()
 q, w, d = [], [], []
+marks = os.environ.get("CALL_MARKS", "1") != "0"   # CALL_MARKS=0: no stream marks around the call
 for trial in range(30):
     ctx.opt_reset()     # every trial the same n generations of a fresh query
     ctx.synchronize()
     t0 = time.perf_counter()
-    ctx.stream_mark(0)
+    if marks: ctx.stream_mark(0)
     ctx.run(n)
     t1 = time.perf_counter()
-    ctx.stream_mark(1)
+    if marks: ctx.stream_mark(1)
     ctx.synchronize()
     t2 = time.perf_counter()
-    q.append((t1 - t0) * 1e6); w.append((t2 - t0) * 1e6); d.append(ctx.stream_elapsed() * 1e3)
+    q.append((t1 - t0) * 1e6); w.append((t2 - t0) * 1e6); d.append(ctx.stream_elapsed() * 1e3 if marks else 0.0)
 med = lambda v: sorted(v)[len(v) // 2]
 print("n = %d (%s): queueing %.1f us, wall to completion %.1f us (%.2f per generation), device between marks %.1f us (%.2f per generation)"
       % (n, os.environ.get("LMCMA_HIP_GRAPH_GENS", "default"), med(q), med(w), med(w) / n, med(d), med(d) / n))

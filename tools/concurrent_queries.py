@@ -52,6 +52,10 @@ def batch_main(argv):
         print("Q=%3d  %.3e candidate-trajectories/s  %.2f us per generation (all queries)  %.2f us per query  %.1f GB/s "
               "algorithmic (%.3f of 8 TB/s)" % (Q, rate, el / gens * 1e6, el / gens * 1e6 / Q, rate * b / 1e9,
                                                rate * b / 8e12), flush=True)
+        if Q == 1:   # the bits the run ended in (to compare builds and switches)
+            st = c.opt_get()
+            print("       final state: sigma %r  best_f %r  sum(xmean) %r  itr %d" % (st["sigma"], st["best_f"],
+                                                                                 float(st["xmean"].sum()), st["itr"]), flush=True)
         c.close()
 
 
