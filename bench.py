@@ -214,11 +214,13 @@ def main():
     ap.add_argument("--sharded-loop", action="store_true",
                     help="N = 1 only: go through lmcma_hip_run_sharded with a one-rank RCCL communicator, i.e. "
                     "what every rank of an N > 1 job runs (not the headline: the graph-replayed lmcma_hip_run is)")
-    ap.add_argument("--exchange", default="peer", choices=["peer", "library", "torch"],
+    ap.add_argument("--exchange", default="peer", choices=["peer", "library", "torch", "rows"],
                     help="N > 1: 'peer' = the sharded loop inside the library with the direct exchange (every shard "
                     "stores its blocks into the peers' mailboxes, the consuming kernels wait for arrival counters); "
                     "'library' = the same loop with two RCCL all-gathers per generation; 'torch' = the loop driven "
-                    "from Python with torch.distributed all-gathers (a rehearsal form)")
+                    "from Python with torch.distributed all-gathers (a rehearsal form); 'rows' = the rows exchange: every "
+                    "rank holds the whole population, samples its range, and RCCL all-gathers rows and costs (the state "
+                    "is one context's bit for bit whatever N; the slow, G-independent form)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="let the ranks share the GPUs when the node has fewer than --gpus (a rehearsal of the N > 1 "
                     "path, not a measurement: backend gloo, the direct exchange over IPC on one device)")
@@ -256,8 +258,8 @@ def main():
         if not args.oversubscribe:
             raise SystemExit("%d ranks on %d GPU(s): --oversubscribe is needed for that" % (world, torch.cuda.device_count()))
         args.backend = "gloo"       # RCCL refuses two ranks on one device
-        if args.exchange == "library":
-            raise SystemExit("--oversubscribe: the RCCL exchange cannot run with ranks sharing a GPU")
+        if args.exchange in ("library", "rows"):
+            raise SystemExit("--oversubscribe: the RCCL exchanges cannot run with ranks sharing a GPU")
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -271,18 +273,20 @@ def main():
     prob = grids.benchmark_problem(args.config)
     lam_local = prob.lam if args.config <= 3 else prob.lam // 8   # cfg4/5 are quoted as 8-GPU populations
     lam_total = lam_local * world
-    native = world > 1 and args.exchange in ("peer", "library")
+    native = world > 1 and args.exchange in ("peer", "library", "rows")
     have_rccl = world > 1 and args.backend == "nccl"
-    if world > 1 and args.exchange == "library" and not have_rccl:
-        raise SystemExit("--exchange library needs --backend nccl")
+    if world > 1 and args.exchange in ("library", "rows") and not have_rccl:
+        raise SystemExit("--exchange %s needs --backend nccl" % args.exchange)
+    rows_form = world > 1 and args.exchange == "rows"
     stream = None
     if world > 1 and not native:
         # kernels and collectives are ordered on one non-default torch stream
         tstream = torch.cuda.Stream(device)
         torch.cuda.set_stream(tstream)
         stream = tstream.cuda_stream
-    ctx = hip.HipContext(prob.N, lam_total, prob.m, dims=prob.dims, waypoints=prob.W, lambda_local=lam_local,
-                         first_candidate=rank * lam_local, seed=42, start=prob.start, goal=prob.goal,
+    ctx = hip.HipContext(prob.N, lam_total, prob.m, dims=prob.dims, waypoints=prob.W,
+                         lambda_local=lam_total if rows_form else lam_local,
+                         first_candidate=0 if rows_form else rank * lam_local, seed=42, start=prob.start, goal=prob.goal,
                          w_len=prob.weights[0], w_grid=prob.weights[1], w_smooth=prob.weights[2],
                          device=local_rank, stream=stream, queries=args.queries)
     ctx.set_grid(prob.cells)
@@ -386,7 +390,7 @@ def main():
                 else:
                     exchange_check = "not checked (no RCCL with ranks sharing a GPU)"
             else:
-                exchange_used, exchange_check = "library", None
+                exchange_used, exchange_check = args.exchange, None
 
         def run_steps(k):
             done = 0
@@ -515,7 +519,9 @@ def main():
                        "lambda_total": lam_total, "m": prob.m, "queries_in_flight": args.queries,
                        "z_source": "philox4x32-10",
                        "update": "on device, fp64", "episode_generations": EPISODE,
-                       "exchange": ("sorted local costs + one row of N+2 doubles per shard (elite partial sum, "
+                       "exchange": "the candidates' rows and costs, two RCCL all-gathers in place; every rank ranks and "
+                                   "recombines the whole population" if exchange_used == "rows" else
+                                   ("sorted local costs + one row of N+2 doubles per shard (elite partial sum, "
                                     "success-rule count, lowest cost), " +
                                     {"peer": "stored by each shard into the peers' mailboxes (fine-grained memory mapped "
                                              "over IPC, arrival counters, the consuming kernels wait at their head)",

@@ -330,6 +330,35 @@ int lmcma_hip_peer_disconnect(lmcma_hip_ctx *ctx);
 int lmcma_hip_peer_status(lmcma_hip_ctx *ctx, int *fine_grained, int *wait_error);
 int lmcma_hip_run_sharded_group(lmcma_hip_ctx **ctxs, int world, int n_generations);
 
+/* ---- the rows exchange: every rank holds the whole population --------------------------
+ * The other way to spread a population over G ranks: the candidates' ROWS are all-gathered,
+ * not the ranks' partial sums.  Every rank's context is created for the whole population
+ * (lambda_local = lambda_total, first_candidate = 0), samples and scores only its range
+ * [rank * lambda_total / G, (rank + 1) * lambda_total / G), receives the other ranges' rows
+ * and costs by all-gather (in place, at their positions in the context's buffers), and then
+ * ranks, recombines and updates exactly as a single context does: L/lmcma.cpp:313-329
+ * (the mean from the mu best rows of arx in rank order) over the whole of arx.  A
+ * candidate's row depends on its global index only (the Philox counter), so the state and
+ * every row are those of lmcma_hip_run on one context, bit for bit, for any G.  The price
+ * is the traffic (lambda_total * row stride * 4 bytes received per rank and generation
+ * instead of G * (N + 2) * 8) and that every rank ranks the whole population; the
+ * partial-sum exchange above is the fast form, this one the form whose result does not
+ * depend on G.
+ *
+ * lmcma_hip_phase_local_range  sample + score candidates [first, first + count) of a
+ *                            context that ranks its candidates itself (first and count
+ *                            multiples of 4); the other rows and costs stay as they are.
+ *                            Then: copy the other ranges in (LMCMA_BUF_ROWS_LOCAL,
+ *                            LMCMA_BUF_COST_ALL), phase_rank, phase_update(0).
+ * lmcma_hip_comm_init / comm_attach  accept such a context when world > 1, lambda_total is a
+ *                            multiple of world and the range a multiple of 16 candidates;
+ *                            lmcma_hip_run_sharded then runs this form (two all-gathers per
+ *                            generation: rows, costs).
+ * lmcma_hip_run_sharded_group  likewise when the G contexts each hold the whole population:
+ *                            the ranges travel as device-to-device copies.
+ * lmcma_hip_get_terms of such a context covers the own range only.                          */
+int lmcma_hip_phase_local_range(lmcma_hip_ctx *ctx, int first, int count);
+
 typedef struct {
     int32_t itr;          /* generations completed (L/lmcma.hpp:60)              */
     int32_t iterator_sz;  /* active direction vectors                            */

@@ -153,6 +153,7 @@ SIGNATURES = {
     "lmcma_hip_queries": (_i, [_vp]),
     "lmcma_hip_run": (_i, [_vp, _i]),
     "lmcma_hip_phase_local": (_i, [_vp]),
+    "lmcma_hip_phase_local_range": (_i, [_vp, _i, _i]),
     "lmcma_hip_phase_rank": (_i, [_vp]),
     "lmcma_hip_phase_update": (_i, [_vp, _i]),
     "lmcma_hip_comm_unique_id": (_i, [ctypes.c_char_p]),

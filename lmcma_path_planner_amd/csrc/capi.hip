@@ -162,6 +162,9 @@ struct lmcma_hip_ctx {
     float *best = nullptr;                      // a shard: lowest cost of the population
     bool ranked_local_only = false;             // the last ranking covered the local candidates only
     bool pre_done = false;   // the first part of this generation's update ran with a ranking launch
+    // the candidates the next sampling launch covers, relative to the local ones (gen_count < 0: all of
+    // them): a context that holds a whole population of which it samples one rank's range
+    int gen_first = 0, gen_count = -1;
     // the word on which workgroup 0 of a sampling launch that carries the previous generation's
     // update waits for the other workgroups (GenParams::fused_counter); zero between launches
     unsigned *fused_counter = nullptr;
@@ -215,6 +218,7 @@ struct lmcma_hip_ctx {
     int peer_arrivals = 0;                 // increments per destination the last producer made
     PeerWait wait_costs{}, wait_rows{};
     hipEvent_t group_ev[2] = {nullptr, nullptr};   // lmcma_hip_run_sharded_group: this shard's two hand-over points
+    bool group_copied = false;                     // ... the rows form has recorded group_ev[1] (its copies of the others' ranges)
 
     hipGraphExec_t graph_exec[2][kGraphKinds] = {};  // [buffer parity at the start][length]
     hipGraph_t graph[2][kGraphKinds] = {};
@@ -409,14 +413,15 @@ int do_generate(lmcma_hip_ctx *c, const UpdateArgs *post = nullptr, bool *post_d
 {
     Timed tm(c, LMCMA_K_GENERATE);
     GenParams g{};
-    g.rows = c->rows;
+    const int gf = c->gen_count >= 0 ? c->gen_first : 0, gn = c->gen_count >= 0 ? c->gen_count : c->nloc;
+    g.rows = c->rows + (size_t)gf * c->ld;
     g.xmean = c->xmean_f; g.V = c->V_f; g.B = c->B_f; g.lo = c->lo_f; g.hi = c->hi_f;
     g.sc = c->sc;
-    g.ld = c->ld; g.n_local = c->nloc; g.m = c->m;
-    g.first_candidate = (uint32_t)c->first;
+    g.ld = c->ld; g.n_local = gn; g.m = c->m;
+    g.first_candidate = (uint32_t)(c->first + gf);
     g.key0 = (uint32_t)c->cfg.seed;
     g.key1 = (uint32_t)(c->cfg.seed >> 32);
-    g.cost = cost_params(c, c->rows, c->nloc, local_costs(c), c->terms);
+    g.cost = cost_params(c, g.rows, gn, local_costs(c) + gf, c->terms ? c->terms + 3 * (size_t)gf : nullptr);
     if (c->have_cov) g.cov = c->cov;
     g.batch = batch_of(c);
     g.fused_counter = c->fused_counter;
@@ -1497,6 +1502,35 @@ int lmcma_hip_phase_local(lmcma_hip_ctx *c)
     return rc;
 }
 
+namespace {
+
+// sample + score candidates [first, first + count) of the local ones; the rest is left as it is
+int generate_range(lmcma_hip_ctx *c, int first, int count)
+{
+    if (!c->fused) return fail(LMCMA_HIP_ERR_STATE, "a range of candidates needs the one-launch sampling path (LMCMA_HIP_FUSED=0 is set)");
+    if (first < 0 || count < 1 || first + count > c->nloc || (first & 3) || (count & 3))
+        return fail(LMCMA_HIP_ERR_ARG, "the range must lie inside the local candidates and start and end on a multiple of 4");
+    c->gen_first = first;
+    c->gen_count = count;
+    const int rc = do_generate(c);
+    c->gen_first = 0;
+    c->gen_count = -1;
+    return rc;
+}
+
+}  // namespace
+
+int lmcma_hip_phase_local_range(lmcma_hip_ctx *c, int first, int count)
+{
+    CTX_TRY(c);
+    int rc = phase_local_checks(c);
+    if (rc != LMCMA_HIP_OK) return rc;
+    if (c->merge_protocol || c->Q > 1)
+        return fail(LMCMA_HIP_ERR_STATE, "phase_local_range: for a context that ranks its candidates itself (not a shard that "
+                                         "exchanges sorted lists, not several queries)");
+    return generate_range(c, first, count);
+}
+
 int lmcma_hip_phase_rank(lmcma_hip_ctx *c)
 {
     CTX_TRY(c);
@@ -1620,14 +1654,27 @@ const RcclApi *rccl_api()
             return fail(LMCMA_HIP_ERR_RUNTIME, std::string(#expr) + ": " + (api)->GetErrorString(_r)); \
     } while (0)
 
+// A context that holds the WHOLE population (lambda_local = lambda_total) as one of `world` > 1
+// ranks: the rows exchange.  It samples and scores its rank's range of candidates only; the other
+// ranges' rows and costs arrive by all-gather, and it ranks and recombines the whole population
+// itself, exactly as a single context does (L/lmcma.cpp:313-329 over all of arx), so the state
+// is the single context's bit for bit whatever the number of ranks.
+bool whole_population_member(const lmcma_hip_ctx *c, int world)
+{
+    return world > 1 && c->Q == 1 && c->nloc == c->lambda && c->first == 0 && c->lambda % world == 0 &&
+           (c->lambda / world) % 16 == 0;
+}
+
 int check_shard(const lmcma_hip_ctx *c, int world, int rank)
 {
     if (world < 1 || world > kMaxPartials || rank < 0 || rank >= world)
         return fail(LMCMA_HIP_ERR_ARG, "comm: world must be in [1, 64] and rank in [0, world)");
     if (c->Q > 1) return fail(LMCMA_HIP_ERR_STATE, "comm: a context with several queries is not a shard");
+    if (whole_population_member(c, world)) return LMCMA_HIP_OK;
     if ((long)c->nloc * world != c->lambda || c->first != rank * c->nloc)
-        return fail(LMCMA_HIP_ERR_STATE, "comm: the context is not this rank's shard (lambda_total = world * "
-                                         "lambda_local and first_candidate = rank * lambda_local are needed)");
+        return fail(LMCMA_HIP_ERR_STATE, "comm: the context is neither this rank's shard (lambda_total = world * lambda_local "
+                                         "and first_candidate = rank * lambda_local) nor a whole population that "
+                                         "world ranks can divide into ranges of a multiple of 16 candidates");
     return LMCMA_HIP_OK;
 }
 
@@ -1889,6 +1936,22 @@ int sharded_generation(lmcma_hip_ctx *c, const RcclApi *api, bool update_due = f
     return leave_update ? LMCMA_HIP_OK : lmcma_hip_phase_update(c, c->world);
 }
 
+// One generation of the rows exchange (whole_population_member): this rank's range sampled and
+// scored, rows and costs of all ranges gathered in place, then the whole population ranked,
+// recombined and the state updated as in a single context.
+int gathered_generation(lmcma_hip_ctx *c, const RcclApi *api)
+{
+    const int cnt = c->lambda / c->world, first = c->rank * cnt;
+    int rc = phase_local_checks(c);
+    if (rc == LMCMA_HIP_OK) rc = generate_range(c, first, cnt);
+    if (rc != LMCMA_HIP_OK) return rc;
+    RCCL_TRY(api, api->AllGather(c->rows + (size_t)first * c->ld, c->rows, (size_t)cnt * c->ld, ncclFloat32, c->comm, c->stream));
+    RCCL_TRY(api, api->AllGather(c->cost_all + first, c->cost_all, (size_t)cnt, ncclFloat32, c->comm, c->stream));
+    rc = lmcma_hip_phase_rank(c);
+    if (rc == LMCMA_HIP_OK) rc = lmcma_hip_phase_update(c, 0);
+    return rc;
+}
+
 }  // namespace
 
 int lmcma_hip_peer_handle(lmcma_hip_ctx *c, char handle[LMCMA_HIP_PEER_HANDLE_BYTES])
@@ -2049,6 +2112,17 @@ int lmcma_hip_run_sharded(lmcma_hip_ctx *c, int n_generations)
     if (n_generations < 0) return fail(LMCMA_HIP_ERR_ARG, "negative generation count");
     const RcclApi *api = c->peer_on ? nullptr : rccl_api();
     int left = n_generations;
+    // (LMCMA_HIP_ROWS_EXCHANGE=1: a whole population with a one-rank communicator goes through the rows
+    // exchange too, all-gathers of one rank included: the form's calls, testable on one GPU)
+    static const bool rows_with_one_rank = getenv("LMCMA_HIP_ROWS_EXCHANGE") != nullptr;
+    if (!c->peer_on && (whole_population_member(c, c->world) ||
+                        (rows_with_one_rank && c->world == 1 && c->nloc == c->lambda && c->Q == 1 && c->lambda % 16 == 0))) {
+        for (; left > 0; --left) {
+            const int rc = gathered_generation(c, api);
+            if (rc != LMCMA_HIP_OK) return rc;
+        }
+        return LMCMA_HIP_OK;
+    }
     // Opt-in (LMCMA_HIP_SHARD_GRAPH=1): two generations, collectives included, recorded into one
     // HIP graph and replayed (two because the sorted-cost buffers alternate).  Queuing a generation
     // from the host takes ~17 us without it, well below a sharded generation's device time, so the
@@ -2106,6 +2180,45 @@ int lmcma_hip_run_sharded_group(lmcma_hip_ctx **ctxs, int world, int n_generatio
             if (ctxs[q] == c) return fail(LMCMA_HIP_ERR_ARG, "run_sharded_group: a context is named twice");
         for (hipEvent_t &ev : c->group_ev)
             if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    if (whole_population_member(ctxs[0], world)) {
+        // The rows exchange: every context holds the whole population and samples its range.  ev[0]:
+        // its range is sampled; ev[1]: it has copied the others' ranges (which they may then overwrite).
+        const size_t cnt = ctxs[0]->lambda / world, ld = ctxs[0]->ld;
+        for (int g = 0; g < n_generations; ++g) {
+            for (int r = 0; r < world; ++r) {
+                lmcma_hip_ctx *c = ctxs[r];
+                CTX_TRY(c);
+                int rc = phase_local_checks(c);
+                if (rc != LMCMA_HIP_OK) return rc;
+                // (also across calls: the other contexts may still be copying this one's range of the
+                // call before)
+                for (int p = 0; p < world; ++p)
+                    if (p != r && ctxs[p]->group_copied) HIP_TRY(hipStreamWaitEvent(c->stream, ctxs[p]->group_ev[1], 0));
+                rc = generate_range(c, (int)(r * cnt), (int)cnt);
+                if (rc != LMCMA_HIP_OK) return rc;
+                HIP_TRY(hipEventRecord(c->group_ev[0], c->stream));
+            }
+            for (int r = 0; r < world; ++r) {
+                lmcma_hip_ctx *c = ctxs[r];
+                CTX_TRY(c);
+                for (int p = 0; p < world; ++p) {
+                    if (p == r) continue;
+                    const lmcma_hip_ctx *o = ctxs[p];
+                    HIP_TRY(hipStreamWaitEvent(c->stream, o->group_ev[0], 0));
+                    HIP_TRY(hipMemcpyPeerAsync(c->rows + p * cnt * ld, c->cfg.device, o->rows + p * cnt * ld, o->cfg.device,
+                                               cnt * ld * sizeof(float), c->stream));
+                    HIP_TRY(hipMemcpyPeerAsync(c->cost_all + p * cnt, c->cfg.device, o->cost_all + p * cnt, o->cfg.device,
+                                               cnt * sizeof(float), c->stream));
+                }
+                HIP_TRY(hipEventRecord(c->group_ev[1], c->stream));
+                c->group_copied = true;
+                int rc = lmcma_hip_phase_rank(c);
+                if (rc == LMCMA_HIP_OK) rc = lmcma_hip_phase_update(c, 0);
+                if (rc != LMCMA_HIP_OK) return rc;
+            }
+        }
+        return LMCMA_HIP_OK;
     }
     const size_t nloc = ctxs[0]->nloc, row = ctxs[0]->N + 2;
     for (int g = 0; g < n_generations; ++g) {

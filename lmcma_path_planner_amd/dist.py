@@ -17,6 +17,12 @@ global candidate index, so a candidate's row does not depend on G.  Per generati
 The elite exchange moves each rank's weighted elite sum rather than the elite
 rows themselves: mu = lambda/2 (reference lmcma.cpp:136), so "the rows of the
 elites" is on average half of every shard, while their weighted sum is N doubles.
+
+The other form, ``gathered_generation``, does move the rows: every rank holds the whole
+population, samples its range, all-gathers rows and costs, and ranks and recombines the
+whole population itself (reference lmcma.cpp:313-329 over all of arx).  Its state is
+that of one unsharded context bit for bit, whatever the number of ranks, at the price of
+lambda * row stride * 4 bytes received per rank and generation.
 """
 import numpy as np
 import torch
@@ -54,6 +60,27 @@ class HipShard:
 
     def phase_local(self):
         self.ctx.phase_local()
+
+    def phase_rank(self):
+        self.ctx.phase_rank()
+
+    def phase_update(self, n_partials):
+        self.ctx.phase_update(n_partials)
+
+
+class HipWhole:
+    """A HipContext that holds the whole population (one rank of the rows exchange) plus torch
+    views of the two buffers whose other ranges arrive by all-gather."""
+
+    def __init__(self, ctx, device):
+        self.ctx = ctx
+        self.ld = ctx.row_stride()
+        self.rows_all = alias_tensor(ctx, hipmod.BUF_ROWS_LOCAL, torch.float32, device)   # [lambda][ld]
+        self.cost_all = alias_tensor(ctx, hipmod.BUF_COST_ALL, torch.float32, device)
+        self.lam = self.cost_all.numel()
+
+    def phase_local_range(self, first, count):
+        self.ctx.phase_local_range(first, count)
 
     def phase_rank(self):
         self.ctx.phase_rank()
@@ -100,3 +127,20 @@ def sharded_generation(shard, group=None):
     shard.phase_rank()
     _all_gather(shard.partial_all[: world * shard.partial_len], shard.partial_local, group)
     shard.phase_update(world)
+
+
+def gathered_generation(whole, group=None):
+    """One generation of the rows exchange.  `whole` provides phase_local_range / phase_rank /
+    phase_update, the row stride ld, and the tensors rows_all ([lambda * ld]) and cost_all
+    ([lambda]) of a context that holds the whole population.  Stream rule as above."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    first, count = shard_range(whole.lam, world, rank)
+    whole.phase_local_range(first, count)
+    if world > 1:
+        ld = whole.ld
+        # both in place: the rank's own range lies at its position inside the buffers
+        _all_gather(whole.rows_all[: whole.lam * ld], whole.rows_all[first * ld:(first + count) * ld], group)
+        _all_gather(whole.cost_all, whole.cost_all[first:first + count], group)
+    whole.phase_rank()
+    whole.phase_update(0)

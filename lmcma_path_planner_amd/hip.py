@@ -207,6 +207,10 @@ class HipContext:
     def phase_local(self):
         check_hip(self.lib.lmcma_hip_phase_local(self._h), "lmcma_hip_phase_local")
 
+    def phase_local_range(self, first, count):
+        """Sample + score candidates [first, first + count) of a context that holds a whole population."""
+        check_hip(self.lib.lmcma_hip_phase_local_range(self._h, int(first), int(count)), "lmcma_hip_phase_local_range")
+
     def phase_rank(self):
         check_hip(self.lib.lmcma_hip_phase_rank(self._h), "lmcma_hip_phase_rank")
 

@@ -64,3 +64,41 @@ class CpuShard:
             for p in range(n_partials):
                 xnew += parts[p]
         self.o.update_with_mean(self.cost_all.numpy().astype(np.float64), xnew)
+
+
+class CpuWhole:
+    """Stand-in for one rank of the rows exchange (dist.gathered_generation): the whole population
+    in every rank, the own range sampled and scored here, everything ranked and recombined here."""
+
+    def __init__(self, prob, lam_total, seed):
+        self.N, self.lam, self.seed = prob.N, lam_total, seed
+        self.ld = prob.N
+        self.co = pyoracle.CostOracle(prob.dims, prob.W, prob.cells, prob.start, prob.goal)
+        self.o = pyoracle.OracleLMCMA(prob.N, lam_total, prob.m, initial=prob.x0, lo=prob.lo, hi=prob.hi,
+                                      sigma=prob.sigma0, seed=seed, z_source=pyoracle.Z_GIVEN)
+        self.rows_all = torch.zeros(lam_total * self.ld, dtype=torch.float32)
+        self.cost_all = torch.zeros(lam_total, dtype=torch.float32)
+
+    def phase_local_range(self, first, count):
+        gen = self.o.itr
+        Z = np.zeros((self.lam, self.N))
+        for i in range(first, first + count):
+            Z[i] = pyoracle.philox_normals(self.seed, gen, i, self.N)
+        self.o.sample_given(Z)
+        rows = self.o.arx[first:first + count].astype(np.float32)
+        cost, _ = self.co.cost_rows_f32(rows)
+        self.rows_all[first * self.ld:(first + count) * self.ld].copy_(torch.from_numpy(rows.reshape(-1)))
+        self.cost_all[first:first + count].copy_(torch.from_numpy(np.where(np.isnan(cost), np.inf, cost).astype(np.float32)))
+
+    def phase_rank(self):
+        cost = self.cost_all.numpy().astype(np.float64)
+        order = np.argsort(cost, kind="stable")
+        rows = self.rows_all.numpy().reshape(self.lam, self.ld)
+        acc = np.zeros(self.N)
+        for r in range(self.o.mu):                       # the mu best rows in rank order (lmcma.cpp:321-326)
+            acc += self.o.weights[r] * rows[order[r]].astype(np.float64)
+        self.xnew = acc
+
+    def phase_update(self, n_partials):
+        assert n_partials == 0
+        self.o.update_with_mean(self.cost_all.numpy().astype(np.float64), self.xnew)

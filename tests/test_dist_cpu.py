@@ -70,6 +70,40 @@ def test_sharded_generation_matches_unsharded(world, tmp_path):
         np.testing.assert_allclose(float(r["sigma"]), float(single["sigma"]), rtol=1e-12)
 
 
+def _rows_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpu_shard import CpuWhole
+    from lmcma_path_planner_amd.dist import gathered_generation
+    whole = CpuWhole(_problem(), LAM, seed=42)
+    for _ in range(GENS):
+        gathered_generation(whole)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), xmean=whole.o.xmean, sigma=whole.o.sigma,
+             cost_all=whole.cost_all.numpy(), rows_all=whole.rows_all.numpy(), v=whole.o.v_arr, itr=whole.o.itr)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_rows_exchange_is_the_unsharded_run_bit_for_bit(world, tmp_path):
+    """dist.gathered_generation: every rank holds the whole population and samples its range; rows
+    and costs are all-gathered in place.  State, rows and costs equal the one-rank run exactly."""
+    def run(w, port):
+        out = str(tmp_path / ("rows%d" % w))
+        os.makedirs(out, exist_ok=True)
+        mp.spawn(_rows_worker, args=(w, port, out), nprocs=w, join=True)
+        return [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(w)]
+    single = run(1, 29561)[0]
+    for r in run(world, 29563 + world):
+        assert int(r["itr"]) == GENS
+        for k in ("xmean", "v", "cost_all", "rows_all"):
+            np.testing.assert_array_equal(r[k], single[k], err_msg=k)
+        assert float(r["sigma"]) == float(single["sigma"])
+
+
 def test_shard_range():
     from lmcma_path_planner_amd.dist import shard_range
     assert shard_range(4096 * 8, 8, 3) == (3 * 4096, 4096)

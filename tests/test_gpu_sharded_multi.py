@@ -158,6 +158,99 @@ def test_direct_exchange_over_processes_gives_the_bits_of_the_phase_form(shape, 
     assert "direct exchange over %d processes: identical" % G in out.stdout, out.stdout[-2000:]
 
 
+def make_whole(prob, lam, count, seed=42):
+    """`count` contexts that each hold the whole population of lam candidates."""
+    from lmcma_path_planner_amd import hip
+    ctxs = []
+    for _ in range(count):
+        c = hip.HipContext(prob.N, lam, prob.m, dims=prob.dims, waypoints=prob.W, start=prob.start, goal=prob.goal, seed=seed,
+                           w_len=prob.weights[0], w_grid=prob.weights[1], w_smooth=prob.weights[2])
+        c.set_grid(prob.cells)
+        c.set_bounds(prob.lo, prob.hi)
+        c.opt_init(prob.x0, prob.sigma0)
+        ctxs.append(c)
+    return ctxs
+
+
+ROWS_SHAPES = {  # name: (benchmark problem, candidates of the whole population)
+    "cfg2": (2, 4096),
+    "cfg3": (3, 8192),
+    "cfg2_in_tiles": (2, 32768),      # above one counting tile: ranked in tiles, then merged
+    "cfg1": (1, 128),
+}
+
+
+@pytest.mark.parametrize("shape,G,gens", [("cfg2", 2, 24), ("cfg2", 8, 24), ("cfg3", 4, 40), ("cfg2_in_tiles", 4, 20),
+                                          ("cfg1", 8, 12)])
+def test_rows_exchange_gives_the_bits_of_one_context(shape, G, gens):
+    """The rows exchange (every context holds the whole population, samples its range, receives the
+    other ranges' rows and costs, ranks and recombines everything itself) against ONE context running
+    lmcma_hip_run: state, vectors, all rows and all costs bit for bit, whatever G.  Both ways of
+    driving it: lmcma_hip_run_sharded_group, and phase by phase with the copies made here."""
+    import torch
+    from lmcma_path_planner_amd import dist as shard_mod
+    from lmcma_path_planner_amd import grids, hip
+    cfg, lam = ROWS_SHAPES[shape]
+    prob = grids.benchmark_problem(cfg)
+    one = make_whole(prob, lam, 1)
+    one[0].run(gens)
+    want = snapshot(one) * G
+    one[0].close()
+
+    ctxs = make_whole(prob, lam, G)
+    hip.HipContext.run_sharded_group(ctxs, 1)
+    hip.HipContext.run_sharded_group(ctxs, gens // 2)
+    hip.HipContext.run_sharded_group(ctxs, gens - 1 - gens // 2)
+    got = snapshot(ctxs)
+    for c in ctxs:
+        c.close()
+    assert_same(got, want, gens)
+
+    dev = torch.device("cuda", 0)
+    ctxs = make_whole(prob, lam, G)
+    cnt, ld = lam // G, ctxs[0].row_stride()
+    rows = [shard_mod.alias_tensor(c, hip.BUF_ROWS_LOCAL, torch.float32, dev) for c in ctxs]
+    cost = [shard_mod.alias_tensor(c, hip.BUF_COST_ALL, torch.float32, dev) for c in ctxs]
+    for _ in range(gens):
+        for r, c in enumerate(ctxs):
+            c.phase_local_range(r * cnt, cnt)
+        for c in ctxs:
+            c.synchronize()
+        for r in range(G):
+            for p in range(G):
+                if p != r:
+                    rows[r][p * cnt * ld:(p + 1) * cnt * ld].copy_(rows[p][p * cnt * ld:(p + 1) * cnt * ld])
+                    cost[r][p * cnt:(p + 1) * cnt].copy_(cost[p][p * cnt:(p + 1) * cnt])
+        torch.cuda.synchronize()
+        for c in ctxs:
+            c.phase_rank()
+            c.phase_update(0)
+    got = snapshot(ctxs)
+    for c in ctxs:
+        c.close()
+    assert_same(got, want, gens)
+
+
+def test_rows_exchange_errors():
+    from lmcma_path_planner_amd import _lib, grids, hip
+    prob = grids.benchmark_problem(1)
+    a, b = make_whole(prob, 128, 2)
+    with pytest.raises(_lib.LmcmaError):
+        a.phase_local_range(0, 130)                 # beyond the population
+    with pytest.raises(_lib.LmcmaError):
+        a.phase_local_range(2, 64)                  # not on a multiple of 4
+    shard = make_shards(prob, 2, 64)
+    with pytest.raises(_lib.LmcmaError):
+        shard[0].phase_local_range(0, 64)           # a shard that exchanges sorted lists
+    with pytest.raises(_lib.LmcmaError):
+        hip.HipContext.run_sharded_group([a, shard[1]], 1)      # a whole population and a shard
+    c3 = make_whole(prob, 128, 1)[0]
+    with pytest.raises(_lib.LmcmaError):
+        hip.HipContext.run_sharded_group([a, b, c3], 1)         # 128 candidates do not divide by 3
+    for c in (a, b, c3, *shard):
+        c.close()
+
+
 def test_a_peer_that_never_arrives_is_reported_not_waited_for_forever():
     from lmcma_path_planner_amd import _lib, grids
     prob = grids.benchmark_problem(1)

@@ -120,6 +120,39 @@ def test_recorded_sharded_generations_give_the_same_bits():
     assert "identical" in out.stdout
 
 
+ROWS_SCRIPT = """
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from lmcma_path_planner_amd import grids, hip
+for cfg, lam, gens in ((2, 4096, 30), (3, 2048, 40), (2, 32768, 12)):
+    prob = grids.benchmark_problem(cfg)
+    def make():
+        c = hip.HipContext(prob.N, lam, prob.m, dims=prob.dims, waypoints=prob.W, seed=42, start=prob.start, goal=prob.goal)
+        c.set_grid(prob.cells); c.set_bounds(prob.lo, prob.hi); c.opt_init(prob.x0, prob.sigma0)
+        return c
+    a = make(); a.run(gens)
+    b = make(); b.comm_init(hip.HipContext.comm_unique_id(), 1, 0)
+    b.run_sharded(1); b.run_sharded(gens // 2); b.run_sharded(gens - 1 - gens // 2)
+    sa, sb = a.opt_get(), b.opt_get()
+    assert sa["itr"] == sb["itr"] == gens and sa["sigma"] == sb["sigma"] and sa["best_f"] == sb["best_f"], (cfg, lam)
+    assert np.array_equal(sa["xmean"], sb["xmean"]) and np.array_equal(a.rows(), b.rows()) and np.array_equal(a.costs(), b.costs())
+    a.close(); b.close()
+print("rows exchange with one rank: identical")
+"""
+
+
+def test_rows_exchange_through_the_communicator_with_one_rank():
+    """LMCMA_HIP_ROWS_EXCHANGE=1: a context that holds its whole population runs the rows form of
+    lmcma_hip_run_sharded (its range = everything; the in-place all-gathers of rows and costs over a
+    one-rank communicator) and ends in the bits of lmcma_hip_run.  With G > 1 the same code runs
+    per rank; tests/test_gpu_sharded_multi.py executes G = 2, 4, 8 with device copies in place of RCCL."""
+    env = dict(os.environ, LMCMA_HIP_ROWS_EXCHANGE="1")
+    out = subprocess.run([sys.executable, "-c", ROWS_SCRIPT % ROOT], env=env, capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "identical" in out.stdout
+
+
 def test_class_in_shard_mode_with_one_rank_equals_the_plain_class():
     """LMCMA::setPopulationShard (world 1): step() goes through lmcma_hip_run_sharded."""
     from lmcma_path_planner_amd import grids, hip, planner
