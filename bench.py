@@ -431,10 +431,12 @@ def main():
             # A short timed region is one library call.  Like any caller that steps K generations at
             # a time it has made that call before: the library keeps a graph of a call length it has
             # seen, recorded behind the first such call and replayed from the second on.  A graph's
-            # first two launches cost more than its later ones (tools/short_call.py, 20 generations:
-            # 522 and 508 us, then 496 from the third launch on), hence four rehearsals: the call that
-            # records and three replays.
-            for _ in range(4):
+            # first launches cost more than its later ones (tools/short_call.py, 20 generations: 526,
+            # 508, 504 us ... 496 from the seventh on), hence three rehearsals: the call behind which
+            # the graph is recorded and two replays.  (With --steps 20 --warmup 5 the
+            # timed call then covers generations 65 to 85 of an episode; a fourth rehearsal would put
+            # the episode's end, one reset and a call cut in two, into a region of 20 generations.)
+            for _ in range(3):
                 run_steps(args.steps)
                 fence()
     t0 = time.perf_counter()

@@ -398,6 +398,12 @@ enum {
 };
 int lmcma_hip_buffer(lmcma_hip_ctx *ctx, int which, void **device_ptr, size_t *bytes);
 int lmcma_hip_row_stride(lmcma_hip_ctx *ctx); /* ld: floats between rows */
+/* Waits for the context's stream.  Returns LMCMA_HIP_ERR_RUNTIME when an update that ran at
+ * the head of a sampling launch gave up its bounded wait for the launch's other workgroups
+ * (the kernels report it through a word in pinned host memory, so no copy is needed to see
+ * it): the state is that of the last good generation and stays so; lmcma_hip_run refuses
+ * further generations, lmcma_hip_opt_get reports the same, lmcma_hip_opt_reset / opt_init
+ * start anew.                                                                           */
 int lmcma_hip_synchronize(lmcma_hip_ctx *ctx);
 
 /* Device time of a stretch of work on the context's stream: mark(0) before it is queued,

@@ -81,10 +81,12 @@ __global__ void k_set_sample_scalars(SampleScalars *sc, float sigma, float mk, i
 // back to the state lmcma_hip_opt_init left: mean, step size, empty direction store
 __global__ void k_opt_reset(OptScalars *opt, SampleScalars *sc, const double *xmean0,
                             double *xmean, float *xmean_f, double *pc, int N, int ld,
-                            unsigned long long *psr_accum, size_t qstride, unsigned *fused_counter)
+                            unsigned long long *psr_accum, size_t qstride, unsigned *fused_counter, int *host_flag)
 {
-    // (the counter of the fused update: a launch that gave up leaves it anywhere; not per query)
+    // (the counter of the fused update: a launch that gave up leaves it anywhere; not per query; and
+    // the word in host memory that told of it, cleared here in stream order)
     if (fused_counter && blockIdx.y == 0 && threadIdx.x == 0) *fused_counter = 0u;
+    if (host_flag && blockIdx.y == 0 && threadIdx.x == 0) __hip_atomic_store(host_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const size_t off = (size_t)blockIdx.y * qstride;  // query blockIdx.y of a batch
     shift_ptr(opt, off); shift_ptr(sc, off); shift_ptr(xmean0, off); shift_ptr(xmean, off);
     shift_ptr(xmean_f, off); shift_ptr(pc, off); shift_ptr(psr_accum, off);
@@ -168,6 +170,9 @@ struct lmcma_hip_ctx {
     // the word on which workgroup 0 of a sampling launch that carries the previous generation's
     // update waits for the other workgroups (GenParams::fused_counter); zero between launches
     unsigned *fused_counter = nullptr;
+    // pinned host word the update kernels can write (UpdateArgs::host_flag) and its device address;
+    // null when the mapping could not be made (lmcma_hip_opt_get still reports the failure)
+    int *host_flag = nullptr, *host_flag_dev = nullptr;
     int psr_parts_n = 0;   // per-workgroup success-rule counts the last ranking left at the head of `keys`
     int32_t *perm = nullptr;
     uint64_t *keys = nullptr;
@@ -229,7 +234,9 @@ struct lmcma_hip_ctx {
         int gens = 0, parity = 0;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
+        uint64_t used = 0;   // call_tick of its last launch: the slot used longest ago makes room
     } call_graph[kCallGraphs];
+    uint64_t call_tick = 0;
     // two sharded generations, collectives included (lmcma_hip_run_sharded, opt-in)
     hipGraphExec_t shard_graph_exec = nullptr;
     hipGraph_t shard_graph = nullptr;
@@ -465,6 +472,7 @@ UpdateArgs update_args(const lmcma_hip_ctx *c, const double *partials, int n_par
     a.t = c->t; a.vec = c->vec; a.iterator = c->iterator;
     a.xmean_f = c->xmean_f; a.V_f = c->V_f; a.B_f = c->B_f;
     a.batch = batch_of(c);
+    a.host_flag = c->host_flag_dev;
     return a;
 }
 
@@ -644,6 +652,15 @@ int generations(lmcma_hip_ctx *c, int n)
     return n > 0 ? do_update(c, src, rows, false) : LMCMA_HIP_OK;
 }
 
+// the word the update kernels set in host memory when their bounded wait gives up
+int update_gave_up(const lmcma_hip_ctx *c)
+{
+    if (c->host_flag && *static_cast<volatile const int *>(c->host_flag) == 3)
+        return fail(LMCMA_HIP_ERR_RUNTIME, "an update gave up waiting for the other workgroups of its launch; the state is stale "
+                                           "(lmcma_hip_opt_reset or lmcma_hip_opt_init starts anew)");
+    return LMCMA_HIP_OK;
+}
+
 int check_ctx(const lmcma_hip_ctx *c)
 {
     if (!c) return fail(LMCMA_HIP_ERR_ARG, "null context");
@@ -746,6 +763,19 @@ int lmcma_hip_create(const lmcma_hip_config *cfg, lmcma_hip_ctx **out)
         if (e != hipSuccess) { delete c; return fail(LMCMA_HIP_ERR_RUNTIME, "hipStreamCreate failed"); }
         c->own_stream = true;
     }
+    {
+        void *h = nullptr, *dptr = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess) {
+            memset(h, 0, 64);
+            if (hipHostGetDevicePointer(&dptr, h, 0) == hipSuccess) {
+                c->host_flag = static_cast<int *>(h);
+                c->host_flag_dev = static_cast<int *>(dptr);
+            } else {
+                (void)hipHostFree(h);
+            }
+        }
+        (void)hipGetLastError();
+    }
     const size_t ld = c->ld, N = c->N, nloc = c->nloc, lam = c->lambda, m = c->m;
     // the small, hot buffers first; the candidate rows (the only large one) last
     Arena ar;
@@ -835,6 +865,7 @@ int lmcma_hip_destroy(lmcma_hip_ctx *c)
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->host_flag) (void)hipHostFree(c->host_flag);
     delete c;
     return LMCMA_HIP_OK;
 }
@@ -1279,6 +1310,7 @@ int lmcma_hip_opt_init(lmcma_hip_ctx *c, const double *xmean0, double sigma0)
     }
     c->have_weights = true;
     HIP_TRY(hipStreamSynchronize(nullptr));  // the fills above: done before the context's stream is used
+    if (c->host_flag) *static_cast<volatile int *>(c->host_flag) = 0;  // (the stream was drained above)
     c->sigma0 = sigma0;
     c->opt_ready = true;
     c->pre_done = false;
@@ -1291,8 +1323,14 @@ int lmcma_hip_opt_reset(lmcma_hip_ctx *c)
     CTX_TRY(c);
     if (!c->opt_ready) return fail(LMCMA_HIP_ERR_STATE, "opt_init must come first");
     c->pre_done = false;
+    if (c->host_flag && *static_cast<volatile int *>(c->host_flag) != 0) {
+        // an update has given up: the reset kernel below clears the word in stream order, but the
+        // calls that follow look at it at once, so the (failed) work is waited for and it is cleared here
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        *static_cast<volatile int *>(c->host_flag) = 0;
+    }
     hipLaunchKernelGGL(k_opt_reset, dim3(1, c->Q), dim3(256), 0, c->stream, c->opt, c->sc, c->xmean0,
-                       c->xmean, c->xmean_f, c->pc, c->N, c->ld, c->psr_accum, c->qstride, c->fused_counter);
+                       c->xmean, c->xmean_f, c->pc, c->N, c->ld, c->psr_accum, c->qstride, c->fused_counter, c->host_flag_dev);
     HIP_TRY(hipGetLastError());
     return LMCMA_HIP_OK;
 }
@@ -1311,7 +1349,7 @@ int lmcma_hip_opt_set_query(lmcma_hip_ctx *c, int query, const double *xmean0, d
     hipLaunchKernelGGL(k_opt_reset, dim3(1, 1), dim3(256), 0, c->stream, opt, query_ptr(c, c->sc, query),
                        query_ptr(c, c->xmean0, query), query_ptr(c, c->xmean, query), query_ptr(c, c->xmean_f, query),
                        query_ptr(c, c->pc, query), c->N, c->ld, query_ptr(c, c->psr_accum, query), (size_t)0,
-                       (unsigned *)nullptr);
+                       (unsigned *)nullptr, (int *)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LMCMA_HIP_OK;
@@ -1362,6 +1400,10 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
         return fail(LMCMA_HIP_ERR_STATE, "run needs z_source PHILOX and cost_source TRAJECTORY");
     if (!c->grid) return fail(LMCMA_HIP_ERR_STATE, "set_grid must come first");
     if (n_generations < 0) return fail(LMCMA_HIP_ERR_ARG, "negative generation count");
+    {
+        const int rc = update_gave_up(c);   // (as far as the device has got: nothing is waited for)
+        if (rc != LMCMA_HIP_OK) return rc;
+    }
     int left = n_generations;
     static const bool no_graph = getenv("LMCMA_HIP_NO_GRAPH") != nullptr;  // (read once, not per call)
     const bool use_graph = !c->timing && !no_graph;
@@ -1407,6 +1449,7 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
     if (use_graph && left > 0 && left == n_generations)
         for (auto &cg : c->call_graph)
             if (cg.exec && cg.gens == left && cg.parity == c->parity) {
+                cg.used = ++c->call_tick;
                 HIP_TRY(hipGraphLaunch(cg.exec, c->stream));
                 if (left & 1) {
                     c->parity ^= 1;
@@ -1434,20 +1477,32 @@ int lmcma_hip_run(lmcma_hip_ctx *c, int n_generations)
         bool piece = false, have = false;
         for (int q = 0; q < kGraphKinds; ++q) piece = piece || c->graph_gens[q] == n_generations;
         for (auto &cg : c->call_graph) have = have || (cg.exec && cg.gens == n_generations && cg.parity == c->parity);
-        if (!piece && !have)
-            for (auto &cg : c->call_graph)
-                if (!cg.exec) {
-                    // (the call's own work is queued already: a graph that cannot be recorded is
-                    // done without, the call has not failed)
-                    if (record_generations(c, n_generations, c->parity, &cg.graph, &cg.exec) != LMCMA_HIP_OK) {
-                        if (cg.graph) (void)hipGraphDestroy(cg.graph);
-                        cg = lmcma_hip_ctx::CallGraph{};
-                    } else {
-                        cg.gens = n_generations;
-                        cg.parity = c->parity;
-                    }
-                    break;
-                }
+        if (!piece && !have) {
+            // a free slot, else the one whose graph was launched longest ago (one-off lengths, such
+            // as the pieces an episode boundary cuts a call into, must not hold the slots for good)
+            lmcma_hip_ctx::CallGraph *slot = &c->call_graph[0];
+            for (auto &cg : c->call_graph) {
+                if (!cg.exec) { slot = &cg; break; }
+                if (cg.used < slot->used) slot = &cg;
+            }
+            if (slot->exec) {
+                // (its last launch may still be running: a graph in flight must not be destroyed)
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                (void)hipGraphExecDestroy(slot->exec);
+                if (slot->graph) (void)hipGraphDestroy(slot->graph);
+                *slot = lmcma_hip_ctx::CallGraph{};
+            }
+            // (the call's own work is queued already: a graph that cannot be recorded is done
+            // without, the call has not failed)
+            if (record_generations(c, n_generations, c->parity, &slot->graph, &slot->exec) != LMCMA_HIP_OK) {
+                if (slot->graph) (void)hipGraphDestroy(slot->graph);
+                *slot = lmcma_hip_ctx::CallGraph{};
+            } else {
+                slot->gens = n_generations;
+                slot->parity = c->parity;
+                slot->used = ++c->call_tick;
+            }
+        }
     }
     return LMCMA_HIP_OK;
 }
@@ -2340,12 +2395,12 @@ int lmcma_hip_synchronize(lmcma_hip_ctx *c)
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t e = hipStreamQuery(c->stream);
-        if (e == hipSuccess) return LMCMA_HIP_OK;
+        if (e == hipSuccess) return update_gave_up(c);
         if (e != hipErrorNotReady) HIP_TRY(e);
         if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1)) break;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return LMCMA_HIP_OK;
+    return update_gave_up(c);
 }
 
 int lmcma_hip_stream_mark(lmcma_hip_ctx *c, int which)

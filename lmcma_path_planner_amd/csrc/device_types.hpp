@@ -286,6 +286,9 @@ struct UpdateArgs {
     float *xmean_f;             // [ld]
     float *V_f, *B_f;           // [m][ld] in iterator order, B = M^(k-1-t) nj pc
     Batch batch;
+    // a word in host memory the device can write (or null): set to 3 when an update that runs at the
+    // head of a sampling launch gives up its bounded wait, so that the host sees it without a copy
+    int *host_flag;
 };
 hipError_t launch_update(hipStream_t s, const UpdateArgs &a);
 // The update in two launches (update_body.hpp): vectors that do not depend on this generation's

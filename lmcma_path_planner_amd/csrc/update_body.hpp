@@ -1293,7 +1293,10 @@ __device__ __forceinline__ bool update_post_body(const UpdateArgs &a, double *s_
         stores_ok = s_go != 0;
         if (tid == 0) {
             *fo->counter = 0u;
-            if (!stores_ok) o.done = 3;  // reported by the host as an error; the state is left as it was
+            if (!stores_ok) {
+                o.done = 3;  // reported by the host as an error; the state is left as it was
+                if (a.host_flag) __hip_atomic_store(a.host_flag, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 

@@ -1094,7 +1094,13 @@ lib = _lib.load()
 lib.lmcma_hip_diag_skip_report.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.lmcma_hip_diag_skip_report(ctx._h, 1) == 0
 ctx.run(4)                                   # one workgroup withholds its report: the storing one gives up
-ctx.synchronize()
+for call in (ctx.synchronize, lambda: ctx.run(1)):     # a caller that never reads the state sees it too
+    try:
+        call()
+        print("NO ERROR REPORTED")
+        sys.exit(1)
+    except _lib.LmcmaError as e:
+        assert "gave up" in str(e), str(e)
 try:
     ctx.opt_get()
     print("NO ERROR REPORTED")
@@ -1116,6 +1122,7 @@ for k in ("pc", "pc_arr", "iterator"):
 assert lib.lmcma_hip_diag_skip_report(ctx._h, 0) == 0
 ctx.opt_reset()
 ctx.run(5)
+ctx.synchronize()
 st = ctx.opt_get()
 assert st["itr"] == 5 and np.isfinite(st["best_f"])
 print("give-up path: error reported, state intact, reset recovers")
@@ -1127,7 +1134,7 @@ def test_fused_update_give_up_path_reports_and_keeps_the_state():
     """The sampling launch that carries the previous generation's update: its storing workgroup waits
     (bounded) for every other workgroup's report before it overwrites the state.  In the diagnostic
     build one workgroup can be made to withhold its report: the wait gives up, nothing is stored,
-    lmcma_hip_opt_get returns the error, what that update was to replace (mean, step size, paths, slot
+    lmcma_hip_synchronize, the next lmcma_hip_run and lmcma_hip_opt_get return the error, what that update was to replace (mean, step size, paths, slot
     tables of the last good generation) is still there, and lmcma_hip_opt_reset puts the context back
     to work."""
     import os

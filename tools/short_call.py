@@ -51,9 +51,9 @@ for name, cfg in (("marks, library sync, torch sync (bench.py)", (True, True, Tr
                   ("no marks, library sync, torch sync", (False, True, True)),
                   ("no marks, torch sync only", (False, False, True)),
                   ("no marks, library sync only", (False, True, False))):
-    first = [trial(*cfg)[2] for _ in range(3)]
+    first = [trial(*cfg)[2] for _ in range(12)]
     r = [trial(*cfg) for _ in range(40)]
-    print("   first three trials, all done: %s us" % ", ".join("%.1f" % v for v in first))
+    print("   first twelve trials, all done: %s us" % ", ".join("%.1f" % v for v in first))
     q, a, b, d = (med([x[i] for x in r]) for i in range(4))
     print("%-44s call returns %.1f us, library sync done %.1f, all done %.1f us = %.2f per generation; between marks %.1f"
           % (name, q, a, b, b / n, d), flush=True)
