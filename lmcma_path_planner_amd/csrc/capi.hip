@@ -221,6 +221,7 @@ struct lmcma_hip_ctx {
     uint32_t sent_costs = 0, sent_rows = 0; // counter increments per source so far (what the next wait wants)
     bool peer_sending = false;             // inside a generation of the direct form: the producers send
     int peer_arrivals = 0;                 // increments per destination the last producer made
+    bool peer_rows_received = false;       // ... and that producer also waited for and copied the peers' rows
     PeerWait wait_costs{}, wait_rows{};
     hipEvent_t group_ev[2] = {nullptr, nullptr};   // lmcma_hip_run_sharded_group: this shard's two hand-over points
     bool group_copied = false;                     // ... the rows form has recorded group_ev[1] (its copies of the others' ranges)
@@ -411,6 +412,9 @@ int do_evaluate(lmcma_hip_ctx *c)
 
 UpdateArgs update_args(const lmcma_hip_ctx *c, const double *partials, int n_partials, bool rows_with_scalars);
 PeerSend peer_send_table_if_sending(const lmcma_hip_ctx *c, int which);  // n = 0 outside the direct exchange
+// the receiving side of the rows' exchange inside the kernel that sends the row (x.send set, `arrivals`
+// counter increments per source): fills x.gather*; false: that kernel cannot, a launch of its own follows
+bool peer_gather_in_sender(lmcma_hip_ctx *c, FinalExtras &x, int arrivals);
 
 // sample + score in one launch (device Philox stream only).
 // post: the previous generation's update, not yet applied, is to run at the head of this launch
@@ -591,6 +595,9 @@ int do_recombine_final(lmcma_hip_ctx *c, int rows, bool with_scalars)
     // from the one row gives the same bits as updating from the block rows.
     const int threads = c->merge_protocol ? 0 : update_threads(c->N, std::min(c->m, LMCMA_HIP_MAX_VECTORS));
     if (with_scalars) x.send = peer_send_table_if_sending(c, 1);
+    c->peer_rows_received = false;
+    if (x.send.n > 0 && threads == 0 && recombine_final_is_wide(rows, c->N))
+        c->peer_rows_received = peer_gather_in_sender(c, x, (c->N + 15) / 16);
     int arrivals = 0;
     HIP_TRY(launch_recombine_final(c->stream, src, rows, c->N, c->partial_local, threads,
                                    with_scalars ? &x : nullptr, &arrivals));
@@ -1902,7 +1909,9 @@ PeerSend peer_send_table(const lmcma_hip_ctx *c, int which)
             s.flag[d] = mailbox_flags(base) + from;
         } else {
             s.dst[d] = mailbox_rows(base, c->lambda) + (size_t)from * row;
-            s.flag[d] = r == c->rank ? nullptr : mailbox_flags(base) + kMailboxRowFlags + from;
+            // (the own mailbox's counter for the own row moves too: the kernel that sends may be the one
+            // that copies the gathered rows, and its workgroups need each other's strips)
+            s.flag[d] = mailbox_flags(base) + kMailboxRowFlags + from;
         }
     }
     return s;
@@ -1941,6 +1950,20 @@ int peer_receive_rows(lmcma_hip_ctx *c, int arrivals)
                        reinterpret_cast<uint4 *>(c->partial_all), quads);
     HIP_TRY(hipGetLastError());
     return LMCMA_HIP_OK;
+}
+
+bool peer_gather_in_sender(lmcma_hip_ctx *c, FinalExtras &x, int arrivals)
+{
+    static const bool off = getenv("LMCMA_HIP_PEER_GATHER_LAUNCH") != nullptr;   // (a measurement switch)
+    if (off) return false;
+    PeerWait &w = c->wait_rows;
+    w.want = c->sent_rows += (uint32_t)arrivals;
+    x.gather = w;
+    x.gather.self = -1;   // the own row's counter is waited for as well
+    x.gather_src = reinterpret_cast<const uint4 *>(mailbox_rows(c->mailbox, c->lambda));
+    x.gather_dst = reinterpret_cast<uint4 *>(c->partial_all);
+    x.gather_quads = (c->world * (c->N + 2) * (int)sizeof(double) + 15) / 16;   // (both buffers end in slack)
+    return true;
 }
 
 // One generation of a shard, in the three stretches between which the shards exchange.
@@ -1982,7 +2005,7 @@ int sharded_generation(lmcma_hip_ctx *c, const RcclApi *api, bool update_due = f
     c->peer_arrivals = 0;
     if (rc == LMCMA_HIP_OK) rc = lmcma_hip_phase_rank(c);
     if (rc == LMCMA_HIP_OK && c->peer_on) {
-        rc = peer_receive_rows(c, c->peer_arrivals);
+        if (!c->peer_rows_received) rc = peer_receive_rows(c, c->peer_arrivals);
     } else if (rc == LMCMA_HIP_OK) {
         RCCL_TRY(api, api->AllGather(c->partial_local, c->partial_all, (size_t)row, ncclFloat64, c->comm, c->stream));
     }

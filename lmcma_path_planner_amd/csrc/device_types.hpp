@@ -249,7 +249,17 @@ struct FinalExtras {
     // the finished row (N + 2 entries) also goes into these mailboxes; *arrivals_out = workgroups
     // that bump each destination's counter.  n = 0: nowhere.
     PeerSend send;
+    // The receiving side in the same launch (k_recombine_final_wide only; flags = null: not here):
+    // after its own stores every workgroup waits for all sources' row counters, the shard's own
+    // included (its strips come from the launch's other workgroups), and the launch copies the
+    // gathered rows, gather_quads 16-byte units, from the mailbox into the context's buffer.
+    PeerWait gather;
+    const uint4 *gather_src;
+    uint4 *gather_dst;
+    int gather_quads;
 };
+// whether launch_recombine_final(threads = 0) takes the many-workgroup kernel (which can also receive)
+bool recombine_final_is_wide(int rows, int N);
 // threads: the workgroup size whose summation order the result must have (a row that feeds the
 // context's own update: the update's); 0: any fixed order will do (a row that goes into an exchange)
 hipError_t launch_recombine_final(hipStream_t s, const double *block_partials, int rows, int N,

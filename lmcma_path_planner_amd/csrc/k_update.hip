@@ -154,6 +154,10 @@ __global__ __launch_bounds__(256) void k_recombine_final_wide(const double *bloc
         }
     }
     if (x.send.n > 0) peer_arrive(x.send);  // (uniform over the launch)
+    if (x.gather.flags != nullptr) {        // (likewise)
+        peer_wait(x.gather);
+        for (int q = blockIdx.x * 256 + tid; q < x.gather_quads; q += gridDim.x * 256) x.gather_dst[q] = x.gather_src[q];
+    }
 }
 
 // A first level for many partial rows: rows [b chunk, (b + 1) chunk) of src -> row b of dst.
@@ -293,6 +297,8 @@ hipError_t launch_reduce_rows(hipStream_t s, const double *src, int rows, int N,
     return hipGetLastError();
 }
 
+bool recombine_final_is_wide(int rows, int N) { return (N & 1) == 0 && rows >= 32; }
+
 hipError_t launch_recombine_final(hipStream_t s, const double *block_partials, int rows, int N,
                                   double *partial_local, int threads, const FinalExtras *extras, int *arrivals_out)
 {
@@ -301,7 +307,7 @@ hipError_t launch_recombine_final(hipStream_t s, const double *block_partials, i
     if (extras) x = *extras;
     if (arrivals_out) *arrivals_out = 1;
     if (threads == 0) {  // the caller leaves the summation order to this function
-        if ((N & 1) == 0 && rows >= 32) {
+        if (recombine_final_is_wide(rows, N)) {
             if (arrivals_out) *arrivals_out = (N + 15) / 16;
             hipLaunchKernelGGL(k_recombine_final_wide, dim3((N + 15) / 16), dim3(256), 0, s, block_partials, rows, N,
                                partial_local, x, (size_t)0);
