@@ -336,7 +336,7 @@ def _reference_order(costs):
     return np.argsort(c, kind="stable")
 
 
-@pytest.mark.parametrize("lam", [2, 16, 100, 4096, 5000, 65536, 131072])
+@pytest.mark.parametrize("lam", [2, 16, 100, 4096, 5000, 65536, 131072, 1 << 20])   # the last: LMCMA_HIP_MAX_LAMBDA
 def test_select_is_exact(hip, oracle, lam):
     rng = np.random.default_rng(lam)
     costs = rng.gamma(2.0, 500.0, size=lam)
@@ -836,6 +836,42 @@ def test_error_reporting(hip):
     ctx.sample(0, Z)
     assert np.max(np.abs(ctx.rows() - Z)) <= 1e-6
     ctx.close()
+
+
+def test_documented_limits_are_the_limits(hip):
+    """The sizes include/lmcma_hip.h states as maxima are accepted and work; one beyond each is refused
+    with an error, not a fault."""
+    from lmcma_path_planner_amd._lib import LmcmaError
+    tiny = dict(z_source=hip.Z_HOST, cost_source=hip.COST_EXTERNAL)
+    with pytest.raises(LmcmaError, match="lambda_total"):
+        hip.HipContext(4, (1 << 20) + 1, 1, **tiny)
+    with pytest.raises(LmcmaError, match="lambda_total"):
+        hip.HipContext(4, 1, 1, **tiny)
+    with pytest.raises(LmcmaError, match="n_params"):
+        hip.HipContext(513, 16, 4, **tiny)
+    with pytest.raises(LmcmaError, match="m must be"):
+        hip.HipContext(8, 16, 4097, **tiny)
+    with pytest.raises(LmcmaError, match="queries"):
+        hip.HipContext(8, 16, 4, dims=2, waypoints=4, queries=257)
+    # the device-resident update keeps at most 64 direction vectors; the stepwise calls take more
+    c = hip.HipContext(8, 16, 65, dims=2, waypoints=4)
+    with pytest.raises(LmcmaError, match="64 direction vectors"):
+        c.opt_init(np.zeros(8), 1.0)
+    c.close()
+    # 512 parameters, 256 queries of the smallest population the batch path takes, all in one context
+    W = 256
+    start, goal = [15.0, 0.0], [0.0, 15.0]
+    c = hip.HipContext(2 * W, 64, 4, dims=2, waypoints=W, start=start, goal=goal, queries=256, seed=9)
+    c.set_grid(np.zeros((16, 16), dtype=np.uint8))
+    c.set_bounds(np.zeros(2 * W), np.full(2 * W, 15.0))
+    t = np.arange(1, W + 1) / (W + 1)
+    c.opt_init(np.concatenate([start[d] + t * (goal[d] - start[d]) for d in range(2)]), 0.5)
+    c.run(3)
+    for q in (0, 255):
+        c.query_select(q)
+        st = c.opt_get()
+        assert st["itr"] == 3 and np.isfinite(st["best_f"]) and np.all(np.isfinite(st["xmean"]))
+    c.close()
 
 
 def test_two_shards_on_one_gpu_match_the_unsharded_population(hip):
