@@ -388,6 +388,9 @@ def test_recombine_matches_fp64_sum(hip, oracle):
                                                  (512, 64, 16, 20, 2, 256),    # longest vectors, two-part update
                                                  (512, 96, 64, 70, 2, 256),    # largest store: vectors stay in global memory
                                                  (320, 32, 24, 30, 2, 160),    # 20 coordinates per lane, m = 24
+                                                 (40, 50, 6, 14, 2, 20),       # a population no tile size divides
+                                                 (128, 1000, 16, 20, 2, 64),   # the same at the headline's row length
+                                                 (3, 7, 2, 8, 3, 1),           # one waypoint, odd population
                                                  (4, 2, 2, 6, 2, 2)])          # smallest population
 def test_device_update_follows_oracle_generation_by_generation(hip, oracle, N, lam, m, gens, dims, W):
     """Each generation the oracle is handed the device's rows and costs; its fp64
@@ -431,7 +434,7 @@ def test_device_update_follows_oracle_generation_by_generation(hip, oracle, N, l
     ctx.close()
 
 
-@pytest.mark.parametrize("lam,m", [(512, 16), (8192, 16), (8192, 32), (20480, 8)])
+@pytest.mark.parametrize("lam,m", [(512, 16), (8192, 16), (8192, 32), (20480, 8), (1000, 16), (4100, 16), (50, 6)])
 def test_graph_run_equals_phase_by_phase_run(hip, lam, m):
     """lambda = 8192 leaves 256 partial rows (summed in two levels), 20480 goes through the
     sorting path; m = 32 uses the one-kernel update, m <= 16 the two-part one."""
