@@ -301,6 +301,7 @@ def main():
     # episodes, and a reset falls where an episode ends, not where a region starts.
     episode = [0]
     exchange_used, exchange_check = ("torch" if world > 1 else "none"), None
+    ctx_peer_mapped = [False]   # the mailboxes are mapped and the direct form gave the RCCL form's bits
     if world == 1 and args.sharded_loop:
         with stdout_to_stderr():
             ctx.comm_init(hip.HipContext.comm_unique_id(), 1, 0)
@@ -383,7 +384,29 @@ def main():
                     exchange_check = "identical to the RCCL form over 6 generations" if int(okf.item()) == 1 else \
                         "DIFFERS from the RCCL form or timed out: the RCCL form is what was timed"
                     if int(okf.item()) == 1:
-                        ctx.peer_enable(True)
+                        # both forms give the same bits here: the faster one on this node is the one timed
+                        # (the other is timed beside it afterwards, exchange_alternative)
+                        def rate(peer_on, episodes=3):
+                            ctx.peer_enable(peer_on)
+                            ctx.opt_reset()
+                            ctx.run_sharded(40)
+                            ctx.synchronize()
+                            dist.barrier()
+                            t0_ = time.perf_counter()
+                            for _ in range(episodes):       # (episodes as in the timed region: no run into the stop rule)
+                                ctx.opt_reset()
+                                ctx.run_sharded(EPISODE)
+                            ctx.synchronize()
+                            t_ = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=device)
+                            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                            return float(t_.item()) / (episodes * EPISODE) * 1e6
+                        ctx_peer_mapped[0] = True
+                        us_peer, us_rccl = rate(True), rate(False)
+                        use_peer = us_peer <= us_rccl        # (the same figures on every rank: the same choice)
+                        ctx.peer_enable(use_peer)
+                        exchange_used = "peer" if use_peer else "library"
+                        exchange_check += "; %.1f us per generation with the direct exchange, %.1f with RCCL over 300 " \
+                                          "generations: the faster one is what was timed" % (us_peer, us_rccl)
                     else:
                         exchange_used = "library"
                     ctx.opt_reset()
@@ -552,23 +575,22 @@ def main():
             if ref is not None:
                 out["cpu_baseline_reference"] = ref
     alt = None
-    if world > 1 and native and have_rccl and args.exchange == "peer":
+    if world > 1 and native and have_rccl and args.exchange == "peer" and ctx_peer_mapped[0]:
         # the other exchange form on the same contexts, timed the same way (a shorter region)
         other_is_peer = exchange_used != "peer"
-        if not other_is_peer:
-            ctx.peer_enable(other_is_peer)
-            k_alt = min(args.steps, 400)
-            run_steps(100)
-            fence()
-            t0 = time.perf_counter()
-            run_steps(k_alt)
-            fence()
-            el = time.perf_counter() - t0
-            t = torch.tensor([el], dtype=torch.float64, device=rdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            alt = {"exchange": "peer" if other_is_peer else "library (two RCCL all-gathers)",
-                   "value": lam_total * k_alt / float(t.item()), "unit": "candidate-trajectories/s", "steps": k_alt,
-                   "ms_per_step": float(t.item()) / k_alt * 1e3}
+        ctx.peer_enable(other_is_peer)
+        k_alt = min(args.steps, 400)
+        run_steps(100)
+        fence()
+        t0 = time.perf_counter()
+        run_steps(k_alt)
+        fence()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device=rdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        alt = {"exchange": "peer" if other_is_peer else "library (two RCCL all-gathers)",
+               "value": lam_total * k_alt / float(t.item()), "unit": "candidate-trajectories/s", "steps": k_alt,
+               "ms_per_step": float(t.item()) / k_alt * 1e3}
     if rank == 0:
         if alt is not None:
             out["exchange_alternative"] = alt
