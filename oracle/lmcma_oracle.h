@@ -6,12 +6,24 @@
  * baseline leg have an independent fp64 restatement of the reference algorithm
  * to compare the HIP path against.
  *
- * Parity status: the reference translation unit lmcma_path_planner/src/lmcma.cpp
- * cannot be compiled in this image (it includes <eigen3/Eigen/Dense>, which is
- * not installed) and the reference ships no golden vectors, so this restatement
- * is pinned only by the handful of reference outputs that were recorded when
- * the reference was surveyed (tests/golden/reference_probe.json).  Everything
- * not covered by those values is "parity unpinned".
+ * Parity status: PINNED for the optimiser.  The reference translation unit
+ * lmcma_path_planner/src/lmcma.cpp is compiled where it lies by oracle/Makefile
+ * (target `ref`: all of the file but its Eigen include, line 6, and the three
+ * Eigen-based functions at its end, lines 836-864, which the optimiser path
+ * never reaches) into oracle/_ref/, a harness (oracle/ref_harness.cpp) drives it,
+ * and tests/golden/make_reference_fixtures.py records its outputs: the uniform
+ * and Gaussian streams for four seeds, the constants of LMCMA::init, myqsort,
+ * differentiationMatrix, full ask/tell traces (rows, costs, mean, paths,
+ * direction store, slot tables, step size, BestF) with and without bounds, the
+ * stop rule, and the traces of SepCMA and CMAChol.  tests/test_reference_pins.py
+ * checks this restatement against that fixture (and, where oracle/_ref exists,
+ * against the compiled reference itself) bit for bit.
+ * Still "parity unpinned", because no reference output can exist for them here:
+ * covariance() / invert / cholesky / applyCovL (Eigen is not installed), the
+ * trajectory cost integration and the distance transform (they live in OMPL and
+ * dynamicEDT3D, which the reference does not vendor), and runs with fewer stored
+ * direction vectors than candidates (the reference has m = lambda only; the
+ * pinned path is m = lambda, m < lambda is the same code with a shorter store).
  *
  * Each function cites the reference lines it follows, as
  *   L/  = lmcma_path_planner/src/
