@@ -177,8 +177,8 @@ def test_grid_generators(oracle):
 
 
 def test_sepcma_restatement_converges_on_an_ellipsoid(oracle):
-    """SepCMA (lmcma.cpp:466-577) has no recorded reference output: parity unpinned beyond the
-    restated arithmetic; this only checks that the restatement optimises."""
+    """SepCMA (lmcma.cpp:466-577): its traces against the compiled reference are in
+    tests/test_reference_pins.py; this checks that the restatement optimises."""
     n = 10
     scale = np.arange(1, n + 1, dtype=np.float64)
     s = oracle.OracleSepCMA(n, 12, initial=np.full(n, 3.0), sigma=1.0, seed=5)
@@ -189,8 +189,8 @@ def test_sepcma_restatement_converges_on_an_ellipsoid(oracle):
 
 
 def test_cmachol_restatement_converges_on_a_rotated_ellipsoid(oracle):
-    """CMAChol (lmcma.cpp:579-754): parity unpinned like SepCMA; the restatement must optimise a
-    problem a diagonal model cannot (a rotated ellipsoid) and keep A A^-1 = I."""
+    """CMAChol (lmcma.cpp:579-754): pinned like SepCMA (tests/test_reference_pins.py); here the
+    restatement must optimise a problem a diagonal model cannot (a rotated ellipsoid) and keep A A^-1 = I."""
     n = 8
     rng = np.random.default_rng(1)
     Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
